@@ -1,0 +1,199 @@
+/*
+ * photon_beams.h — C ABI of the MI355X photon-beam radiance path.
+ *
+ * The reference (RaeJ/Raytracer) has no FFI: its boundary is the set of free
+ * functions that Source/skeleton.cpp calls on shared globals.  Each entry point
+ * below names the reference interface it replaces (file:line under the
+ * reference tree).  All functions return PB_OK (0) or a negative pb_status and
+ * never throw, print or exit.  Pointers are caller-owned HOST memory unless the
+ * parameter name starts with d_ (then it is device memory on the context's GPU).
+ * A context belongs to one GPU and one host thread at a time.
+ *
+ * Coordinates are the reference's camera space (world space multiplied by the
+ * matrix of TransformationMatrix, skeleton.cpp:512-532); every camera ray
+ * starts at (0,0,0) as in DrawStandard (skeleton.cpp:346).
+ */
+#ifndef PHOTON_BEAMS_H
+#define PHOTON_BEAMS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pb_status {
+  PB_OK = 0,
+  PB_ERR_ARG = -1,        /* null pointer, bad size, bad mode                    */
+  PB_ERR_STATE = -2,      /* call order: scene/segments/LBVH not set yet         */
+  PB_ERR_DEVICE = -3,     /* a HIP call failed; see pb_last_error()              */
+  PB_ERR_NO_DEVICE = -4,  /* no usable GPU: there is no CPU fallback             */
+  PB_ERR_CAPACITY = -5    /* a fixed-size buffer (output array, queue) is small  */
+} pb_status;
+
+/* Run-time form of the compile-time switches and globals of Source/Control.h:4-50
+ * (same names, lower case; same defaults from pb_control_defaults). */
+typedef struct pb_control {
+  int32_t screen_width;     /* SCREEN_WIDTH   512 */
+  int32_t screen_height;    /* SCREEN_HEIGHT  512 */
+  int32_t ssaa;             /* SSAA           1   */
+  int32_t photon_number;    /* PHOTON_NUMBER  1000 */
+  int32_t bounces;          /* BOUNCES        0   */
+  int32_t adaptive;         /* ADAPTIVE       false */
+  int32_t short_beams;      /* SHORT_BEAMS    false */
+  int32_t short_view;       /* SHORT_VIEW     false */
+  int32_t scatter;          /* SCATTER        true  */
+  int32_t one_dimensional;  /* ONE_DIMENSIONAL false */
+  int32_t fixed_radius;     /* FIXED_RADIUS   false */
+  int32_t heterogeneous;    /* HETEROGENEOUS  false */
+  float   radius;           /* RADIUS         0.01f */
+  float   absorbed;         /* ABSORBED       0.0f  */
+  uint32_t seed;            /* SEED           42    */
+  float   light_position[4];/* (0,-0.8,-0.5,1)      */
+  float   light_power[3];   /* 0.5*(1,1,1)          */
+  float   absorption_c;     /* 0.035                */
+  float   scattering_c;     /* 0.005; extinction_c = absorption_c + scattering_c */
+  float   camera[4];        /* (0,0,-3,1)           */
+  float   theta[3];         /* skeleton.cpp:25 (0,0,0) */
+} pb_control;
+
+/* One photon-beam segment: the fields of PhotonSeg (Intersections.h:36-52) that
+ * the radiance estimate reads, plus the box that gates it and its beam's energy.
+ * 28 little-endian words = 112 bytes; also the on-disk dump format. */
+typedef struct pb_segment {
+  float start[3];       /* PhotonSeg.start.xyz                                   */
+  float end[3];         /* PhotonSeg.end.xyz                                     */
+  float orig_start[3];  /* PhotonSeg.orig_start.xyz (start of the whole beam)    */
+  float radius;         /* PhotonSeg.radius                                      */
+  float cull_lo[3];     /* box whose entry distance gates the segment, as the    */
+  float cull_hi[3];     /* min_b/max_b of HitBoundingBox (Intersections.h:85-86):*/
+                        /* the leaf-node box of the reference tree, or the       */
+                        /* segment's own PhotonSeg.min/max box                   */
+  float energy[3];      /* PhotonBeam.energy as BeamRadianceStandard looks it up */
+                        /* (BeamRadiance.h:449-455)                              */
+  float s_ext, e_ext, c_ext; /* PhotonSeg.s_ext/e_ext/c_ext (heterogeneous)      */
+  int32_t seg_id;       /* PhotonSeg.seg_id                                      */
+  int32_t id;           /* PhotonSeg.id (beam index)                             */
+  uint32_t flags;       /* bit0 ada_width, bit1 scattered                        */
+  uint32_t reserved[3];
+} pb_segment;
+
+/* One photon beam: PhotonBeam (CastPhotons.h:14-27) without the unused fields. */
+typedef struct pb_beam {
+  float start[4];
+  float end[4];
+  float omega_u[4];
+  float radius;
+  float energy[3];
+  int32_t index_hit;
+  uint32_t flags;       /* bit0 ada_width, bit1 scattered, bit2 absorbed,
+                           bit3 pushed into beams_scattered (else beams_const)   */
+  uint32_t photon;      /* emitting photon index (0-based)                       */
+  uint32_t order;       /* push order inside that photon                         */
+} pb_beam;
+
+/* LBVH node as downloaded for checking: children >= 0 are internal nodes,
+ * ~child (negative) is the leaf holding sorted position ~child. */
+typedef struct pb_node {
+  float lo[3];
+  float hi[3];
+  int32_t left, right;
+} pb_node;
+
+typedef struct pb_stats {
+  uint64_t rays;             /* camera rays of the last pb_render call            */
+  uint64_t rays_hit_scene;   /* rays for which ClosestIntersection found a hit   */
+  uint64_t candidates;       /* (ray, segment) pairs the kernel evaluated         */
+  uint64_t cyl_hits;         /* pairs with a non-negative discriminant            */
+  uint64_t valid_hits;       /* pairs that contributed radiance                   */
+  uint64_t nodes_visited;    /* LBVH nodes tested by the tile traversal           */
+  float ms_render;           /* device time of the last pb_render (HIP events)    */
+  float ms_build;            /* device time of the last pb_build_lbvh             */
+  float ms_prepare;          /* device time of the last segment upload/prepare    */
+  float ms_emit;             /* device time of the last pb_emit_beams             */
+} pb_stats;
+
+typedef struct pb_ctx pb_ctx;
+
+enum { PB_MODE_721 = 721,      /* BeamRadianceStandard + Integral_721            */
+       PB_MODE_73HET = 73 };   /* BVHBeamRadianceHet + Integral_73Het            */
+
+/* Control.h:4-50 defaults. */
+void pb_control_defaults(pb_control* c);
+
+/* Human-readable text for the last failing call on this thread. */
+const char* pb_last_error(void);
+
+/* Number of usable GPUs; 0 if none (nothing here runs on the CPU). */
+int pb_device_count(void);
+
+/* Create/destroy a context on GPU `device`.  The Control values are copied. */
+int pb_create(const pb_control* control, int device, pb_ctx** out);
+void pb_destroy(pb_ctx* ctx);
+
+/* The Cornell box of LoadTestModel (TestModelH.h:45-214) in world space:
+ * writes 30 triangles as v0,v1,v2 xyz (9 floats each) and, if not NULL, their
+ * normals (3 floats each).  Returns the triangle count (30). */
+int pb_load_test_model(float* tri_xyz, float* normals_xyz, int capacity);
+
+/* TransformationMatrix (skeleton.cpp:512-532): column-major 4x4. */
+void pb_transformation_matrix(const float theta[3], const float camera[4], float matrix[16]);
+
+/* The (matrix, triangles) pair that ClosestIntersection (Intersections.h:458-497)
+ * receives on every call: triangles in world space, matrix as above. */
+int pb_set_scene(pb_ctx* ctx, const float* tri_xyz, int n_tri, const float matrix[16]);
+
+/* The extinction field GRID (Tessendorf.h:16-27) after HeterogeneousRun's
+ * transform (skeleton.cpp:119-125): side*side values of sigma_t. */
+int pb_set_grid(pb_ctx* ctx, const float* sigma_t, int side);
+
+/* The segment set that BuildTree (CastPhotons.h:800-1126) would hold, and the
+ * root box that CastPhotonBeams returns (CastPhotons.h:384-389, un-flipped).
+ * Host and device-pointer forms.  Also derives the per-segment frame that
+ * HitCylinder (Intersections.h:313-328) recomputes on every call. */
+int pb_upload_segments(pb_ctx* ctx, const pb_segment* segs, int n,
+                       const float root_lo[3], const float root_hi[3]);
+int pb_upload_segments_d(pb_ctx* ctx, const pb_segment* d_segs, int n,
+                         const float root_lo[3], const float root_hi[3], void* stream);
+int pb_segment_count(pb_ctx* ctx, int* n_out);
+int pb_download_segments(pb_ctx* ctx, pb_segment* out, int capacity, int* n_out);
+int pb_get_root_box(pb_ctx* ctx, float root_lo[3], float root_hi[3]);
+
+/* CastPhotonBeams (CastPhotons.h:312-390) + BoundPhotonBeams (:144-288) on the
+ * GPU: one photon per lane, counter-based random numbers keyed by
+ * (seed, photon, draw), beams pushed in (photon, order) order.  The result
+ * replaces the context's segment set (own-box cull rule) and root box. */
+int pb_emit_beams(pb_ctx* ctx, int n_photons, uint64_t seed, int* n_beams_out, int* n_segments_out);
+int pb_download_beams(pb_ctx* ctx, pb_beam* out, int capacity, int* n_out);
+
+/* BuildTree (CastPhotons.h:800-1126) replacement: Morton codes of the segment
+ * midpoints, LDS radix sort, Karras hierarchy, bottom-up refit. */
+int pb_build_lbvh(pb_ctx* ctx);
+/* keys[n], perm[n], nodes[n-1] (any may be NULL). */
+int pb_download_lbvh(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes);
+
+/* DrawStandard / DrawHet (skeleton.cpp:330-365, :367-412) for the pixel
+ * rectangle [x0,x0+w) x [y0,y0+h): per pixel ClosestIntersection, then the
+ * beam radiance estimate over the segment set.  Output is current/SSAA per
+ * pixel as RGB, row-major h*w*3 (float: the dvec3 -> vec3 conversion at
+ * PutPixelSDL, SDLauxiliary.h:149).  use_lbvh = 0 scans every segment.  */
+int pb_render(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh, float* rgb_out);
+int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh,
+                float* d_rgb_out, void* stream);
+/* Same, but image rows y = first_row + k*row_stride (k = 0..n_rows-1), full
+ * width: the interleaved row tiles one GPU of several renders. */
+int pb_render_rows_d(pb_ctx* ctx, int first_row, int row_stride, int n_rows, int mode,
+                     int use_lbvh, float* d_rgb_out, void* stream);
+
+/* PutPixelSDL (SDLauxiliary.h:149-161): RGB float -> 0x80RRGGBB, n pixels. */
+int pb_quantise_argb(const float* rgb, int n_pixels, uint32_t* argb_out);
+
+/* Counters and device times of the last calls. Counting slows pb_render, so it
+ * is off unless enabled. */
+int pb_enable_counters(pb_ctx* ctx, int on);
+int pb_counters(pb_ctx* ctx, pb_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHOTON_BEAMS_H */
