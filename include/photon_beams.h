@@ -180,10 +180,11 @@ int pb_download_lbvh(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes
 int pb_render(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh, float* rgb_out);
 int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh,
                 float* d_rgb_out, void* stream);
-/* Same, but image rows y = first_row + k*row_stride (k = 0..n_rows-1), full
- * width: the interleaved row tiles one GPU of several renders. */
-int pb_render_rows_d(pb_ctx* ctx, int first_row, int row_stride, int n_rows, int mode,
-                     int use_lbvh, float* d_rgb_out, void* stream);
+/* Same for the 8-row strips first_strip + k*strip_stride (k = 0..n_strips-1) of
+ * the full-width image, strip s covering rows 8s..8s+7: the interleaved row
+ * tiles one GPU of several renders.  Output rows are packed: 8*n_strips rows. */
+int pb_render_strips_d(pb_ctx* ctx, int first_strip, int strip_stride, int n_strips, int mode,
+                       int use_lbvh, float* d_rgb_out, void* stream);
 
 /* PutPixelSDL (SDLauxiliary.h:149-161): RGB float -> 0x80RRGGBB, n pixels. */
 int pb_quantise_argb(const float* rgb, int n_pixels, uint32_t* argb_out);

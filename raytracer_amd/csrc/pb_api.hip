@@ -1,0 +1,376 @@
+// extern "C" layer of libphoton_beams.so (declarations and reference citations:
+// include/photon_beams.h).  Host code here only moves data, launches kernels and
+// keeps the context; nothing of the radiance path runs on the CPU.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pb_internal.h"
+
+static thread_local std::string g_last_error;
+void pb_set_error(const std::string& msg) { g_last_error = msg; }
+
+struct pb_ctx {
+  pb_control ctl;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};   // pairs: 0,1 render; 2,3 prepare; 4,5 build; 6,7 emit
+  bool ev_valid[4] = {false, false, false, false};
+  // scene
+  float* d_tri_xyz = nullptr;
+  float* d_matrix = nullptr;
+  TriPrep* d_tris = nullptr;
+  int n_tri = 0;
+  float matrix[16];
+  // segments
+  pb_segment* d_segs = nullptr;
+  SegFrame* d_frames = nullptr;
+  float4* d_capA = nullptr;
+  float4* d_capB = nullptr;
+  int n_seg = 0, cap_seg = 0, frame_mode = 0;
+  bool have_segments = false;
+  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+  // output staging for the host-pointer render
+  float* d_out = nullptr;
+  size_t out_floats = 0;
+  // counters
+  unsigned long long* d_counters = nullptr;
+  bool count_on = false;
+  pb_stats stats;
+};
+
+namespace {
+
+int ensure_device(pb_ctx* ctx) {
+  PB_HIP(hipSetDevice(ctx->device));
+  return PB_OK;
+}
+
+// Candidate planes / quadrant flags of HitBoundingBox for the origin (0,0,0)
+// (Intersections.h:95-112); same rule as the device-side gate_setup.
+void host_gate_setup(const float lo[3], const float hi[3], GateBox& g) {
+  uint32_t q = 0;
+  bool inside = true;
+  for (int i = 0; i < 3; ++i) {
+    g.lo[i] = lo[i]; g.hi[i] = hi[i];
+    if (0.0f < lo[i]) { g.cand[i] = lo[i]; inside = false; }
+    else if (0.0f > hi[i]) { g.cand[i] = hi[i]; inside = false; }
+    else { g.cand[i] = 0.0f; q |= (1u << i); }
+  }
+  if (inside) q |= 8u;
+  g.qflags = q;
+}
+
+int ensure_segment_capacity(pb_ctx* ctx, int n) {
+  if (n <= ctx->cap_seg) return PB_OK;
+  int cap = n + n / 8 + 64;
+  if (ctx->d_segs) PB_HIP(hipFree(ctx->d_segs));
+  if (ctx->d_frames) PB_HIP(hipFree(ctx->d_frames));
+  if (ctx->d_capA) PB_HIP(hipFree(ctx->d_capA));
+  if (ctx->d_capB) PB_HIP(hipFree(ctx->d_capB));
+  ctx->d_segs = nullptr; ctx->d_frames = nullptr; ctx->d_capA = nullptr; ctx->d_capB = nullptr; ctx->cap_seg = 0;
+  PB_HIP(hipMalloc(&ctx->d_segs, sizeof(pb_segment) * (size_t)cap));
+  PB_HIP(hipMalloc(&ctx->d_frames, sizeof(SegFrame) * (size_t)cap));
+  PB_HIP(hipMalloc(&ctx->d_capA, sizeof(float4) * (size_t)cap));
+  PB_HIP(hipMalloc(&ctx->d_capB, sizeof(float4) * (size_t)cap));
+  ctx->cap_seg = cap;
+  return PB_OK;
+}
+
+int default_mode(const pb_ctx* ctx) {
+  return (ctx->ctl.heterogeneous && ctx->ctl.one_dimensional) ? PB_MODE_73HET : PB_MODE_721;
+}
+
+int prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
+  PB_HIP(hipEventRecord(ctx->ev[2], s));
+  int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA,
+                                      ctx->d_capB, s);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipEventRecord(ctx->ev[3], s));
+  ctx->ev_valid[1] = true;
+  ctx->frame_mode = mode;
+  return PB_OK;
+}
+
+int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_stride, int mode, int use_lbvh,
+                  float* d_out, hipStream_t s) {
+  if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
+  if (!ctx->have_segments) { pb_set_error("pb_render: no segment set (pb_upload_segments / pb_emit_beams)"); return PB_ERR_STATE; }
+  if (mode != PB_MODE_721 && mode != PB_MODE_73HET) { pb_set_error("pb_render: mode must be PB_MODE_721 or PB_MODE_73HET"); return PB_ERR_ARG; }
+  if (use_lbvh) { pb_set_error("pb_render: pb_build_lbvh has not been called"); return PB_ERR_STATE; }
+  if (ctx->frame_mode != mode) {
+    int rc = prepare_frames(ctx, mode, s);
+    if (rc != PB_OK) return rc;
+  }
+  RenderParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.tris = ctx->d_tris; p.n_tri = ctx->n_tri;
+  p.frames = ctx->d_frames; p.capA = ctx->d_capA; p.capB = ctx->d_capB; p.n_seg = ctx->n_seg;
+  host_gate_setup(ctx->root_lo, ctx->root_hi, p.root);
+  p.width = ctx->ctl.screen_width; p.height = ctx->ctl.screen_height; p.ssaa = ctx->ctl.ssaa;
+  p.focal = (float)(ctx->ctl.screen_width * ctx->ctl.ssaa);      // rasteriser.h:17
+  p.extinction_c = ctx->ctl.absorption_c + ctx->ctl.scattering_c; // Control.h:48
+  p.x0 = x0; p.y0 = y0; p.out_w = out_w; p.out_h = out_h; p.strip_stride = strip_stride;
+  p.tiles_x = (out_w + 7) / 8; p.tiles_y = (out_h + 7) / 8;
+  p.out = d_out;
+  p.counters = ctx->count_on ? ctx->d_counters : nullptr;
+  if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
+  PB_HIP(hipEventRecord(ctx->ev[0], s));
+  int rc = pb_launch_render(p, mode, ctx->count_on, s);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipEventRecord(ctx->ev[1], s));
+  ctx->ev_valid[0] = true;
+  return PB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void pb_control_defaults(pb_control* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->screen_width = 512; c->screen_height = 512; c->ssaa = 1;
+  c->photon_number = 1000; c->bounces = 0; c->adaptive = 0;
+  c->short_beams = 0; c->short_view = 0; c->scatter = 1;
+  c->one_dimensional = 0; c->fixed_radius = 0; c->heterogeneous = 0;
+  c->radius = 0.01f; c->absorbed = 0.0f; c->seed = 42;
+  c->light_position[0] = 0; c->light_position[1] = (float)-0.8; c->light_position[2] = (float)-0.5; c->light_position[3] = 1;
+  c->light_power[0] = c->light_power[1] = c->light_power[2] = 0.5f * 1;
+  c->absorption_c = (float)0.035; c->scattering_c = (float)0.005;
+  c->camera[0] = 0; c->camera[1] = 0; c->camera[2] = -3; c->camera[3] = 1.0f;
+  c->theta[0] = c->theta[1] = c->theta[2] = 0.0f;
+}
+
+const char* pb_last_error(void) { return g_last_error.c_str(); }
+
+int pb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pb_create(const pb_control* control, int device, pb_ctx** out) {
+  if (!control || !out) { pb_set_error("pb_create: null argument"); return PB_ERR_ARG; }
+  if (control->screen_width <= 0 || control->screen_height <= 0 || control->ssaa <= 0) {
+    pb_set_error("pb_create: screen_width, screen_height and ssaa must be positive"); return PB_ERR_ARG;
+  }
+  int n = pb_device_count();
+  if (n <= 0) { pb_set_error("pb_create: no GPU visible; this library has no CPU path"); return PB_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) { pb_set_error("pb_create: device index out of range"); return PB_ERR_ARG; }
+  pb_ctx* ctx = new pb_ctx();
+  ctx->ctl = *control;
+  ctx->device = device;
+  std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+  *out = nullptr;
+  PB_HIP(hipSetDevice(device));
+  PB_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; ++i) PB_HIP(hipEventCreate(&ctx->ev[i]));
+  PB_HIP(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * PB_CNT_N));
+  PB_HIP(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N));
+  PB_HIP(hipMalloc(&ctx->d_matrix, sizeof(float) * 16));
+  *out = ctx;
+  return PB_OK;
+}
+
+void pb_destroy(pb_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
+                  ctx->d_out, ctx->d_counters};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+void pb_transformation_matrix(const float theta[3], const float camera[4], float M[16]) {
+  // skeleton.cpp:512-532, column-major M[col*4+row]
+  float cx = std::cos(theta[0]), sx = std::sin(theta[0]);
+  float cy = std::cos(theta[1]), sy = std::sin(theta[1]);
+  float cz = std::cos(theta[2]), sz = std::sin(theta[2]);
+  M[0] = cy * cz; M[1] = cy * sz; M[2] = -sy; M[3] = 0;
+  M[4] = (-cx * sz) + (sx * sy * cz); M[5] = (cx * cz) + (sx * sy * sz); M[6] = sx * cy; M[7] = 0;
+  M[8] = (sx * sz) + (cx * sy * cz); M[9] = (-sx * cz) + (cx * sy * sz); M[10] = cx * cy; M[11] = 0;
+  M[12] = -camera[0]; M[13] = -camera[1]; M[14] = -camera[2]; M[15] = 1;
+}
+
+int pb_set_scene(pb_ctx* ctx, const float* tri_xyz, int n_tri, const float matrix[16]) {
+  if (!ctx || !tri_xyz || !matrix || n_tri <= 0) { pb_set_error("pb_set_scene: bad argument"); return PB_ERR_ARG; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  if (ctx->d_tri_xyz) { PB_HIP(hipFree(ctx->d_tri_xyz)); ctx->d_tri_xyz = nullptr; }
+  if (ctx->d_tris) { PB_HIP(hipFree(ctx->d_tris)); ctx->d_tris = nullptr; }
+  PB_HIP(hipMalloc(&ctx->d_tri_xyz, sizeof(float) * 9 * (size_t)n_tri));
+  PB_HIP(hipMalloc(&ctx->d_tris, sizeof(TriPrep) * (size_t)n_tri));
+  PB_HIP(hipMemcpyAsync(ctx->d_tri_xyz, tri_xyz, sizeof(float) * 9 * (size_t)n_tri, hipMemcpyHostToDevice, ctx->stream));
+  PB_HIP(hipMemcpyAsync(ctx->d_matrix, matrix, sizeof(float) * 16, hipMemcpyHostToDevice, ctx->stream));
+  rc = pb_launch_prepare_scene(ctx->d_tri_xyz, n_tri, ctx->d_matrix, ctx->d_tris, ctx->stream);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->n_tri = n_tri;
+  std::memcpy(ctx->matrix, matrix, sizeof(float) * 16);
+  return PB_OK;
+}
+
+int pb_set_grid(pb_ctx* ctx, const float* sigma_t, int side) {
+  (void)ctx; (void)sigma_t; (void)side;
+  pb_set_error("pb_set_grid: the heterogeneous path is not implemented yet");
+  return PB_ERR_STATE;
+}
+
+static int upload_common(pb_ctx* ctx, const pb_segment* src, bool src_on_device, int n, const float root_lo[3],
+                         const float root_hi[3], hipStream_t s) {
+  if (!ctx || (!src && n > 0) || n < 0 || !root_lo || !root_hi) { pb_set_error("pb_upload_segments: bad argument"); return PB_ERR_ARG; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  rc = ensure_segment_capacity(ctx, n);
+  if (rc != PB_OK) return rc;
+  if (n > 0)
+    PB_HIP(hipMemcpyAsync(ctx->d_segs, src, sizeof(pb_segment) * (size_t)n,
+                          src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  ctx->n_seg = n;
+  for (int k = 0; k < 3; ++k) { ctx->root_lo[k] = root_lo[k]; ctx->root_hi[k] = root_hi[k]; }
+  rc = prepare_frames(ctx, default_mode(ctx), s);
+  if (rc != PB_OK) return rc;
+  ctx->have_segments = true;
+  return PB_OK;
+}
+
+int pb_upload_segments(pb_ctx* ctx, const pb_segment* segs, int n, const float root_lo[3], const float root_hi[3]) {
+  if (!ctx) { pb_set_error("pb_upload_segments: null context"); return PB_ERR_ARG; }
+  int rc = upload_common(ctx, segs, false, n, root_lo, root_hi, ctx->stream);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipStreamSynchronize(ctx->stream));
+  return PB_OK;
+}
+
+int pb_upload_segments_d(pb_ctx* ctx, const pb_segment* d_segs, int n, const float root_lo[3], const float root_hi[3],
+                         void* stream) {
+  return upload_common(ctx, d_segs, true, n, root_lo, root_hi, (hipStream_t)stream);
+}
+
+int pb_segment_count(pb_ctx* ctx, int* n_out) {
+  if (!ctx || !n_out) { pb_set_error("pb_segment_count: null argument"); return PB_ERR_ARG; }
+  *n_out = ctx->have_segments ? ctx->n_seg : 0;
+  return PB_OK;
+}
+
+int pb_download_segments(pb_ctx* ctx, pb_segment* out, int capacity, int* n_out) {
+  if (!ctx || !out || !n_out) { pb_set_error("pb_download_segments: null argument"); return PB_ERR_ARG; }
+  if (!ctx->have_segments) { pb_set_error("pb_download_segments: no segment set"); return PB_ERR_STATE; }
+  if (capacity < ctx->n_seg) { pb_set_error("pb_download_segments: output array too small"); return PB_ERR_CAPACITY; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipDeviceSynchronize());
+  PB_HIP(hipMemcpy(out, ctx->d_segs, sizeof(pb_segment) * (size_t)ctx->n_seg, hipMemcpyDeviceToHost));
+  *n_out = ctx->n_seg;
+  return PB_OK;
+}
+
+int pb_get_root_box(pb_ctx* ctx, float root_lo[3], float root_hi[3]) {
+  if (!ctx || !root_lo || !root_hi) { pb_set_error("pb_get_root_box: null argument"); return PB_ERR_ARG; }
+  if (!ctx->have_segments) { pb_set_error("pb_get_root_box: no segment set"); return PB_ERR_STATE; }
+  for (int k = 0; k < 3; ++k) { root_lo[k] = ctx->root_lo[k]; root_hi[k] = ctx->root_hi[k]; }
+  return PB_OK;
+}
+
+int pb_emit_beams(pb_ctx* ctx, int n_photons, uint64_t seed, int* n_beams_out, int* n_segments_out) {
+  (void)ctx; (void)n_photons; (void)seed; (void)n_beams_out; (void)n_segments_out;
+  pb_set_error("pb_emit_beams: GPU emission is not implemented yet");
+  return PB_ERR_STATE;
+}
+int pb_download_beams(pb_ctx* ctx, pb_beam* out, int capacity, int* n_out) {
+  (void)ctx; (void)out; (void)capacity; (void)n_out;
+  pb_set_error("pb_download_beams: GPU emission is not implemented yet");
+  return PB_ERR_STATE;
+}
+int pb_build_lbvh(pb_ctx* ctx) {
+  (void)ctx;
+  pb_set_error("pb_build_lbvh: not implemented yet");
+  return PB_ERR_STATE;
+}
+int pb_download_lbvh(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes) {
+  (void)ctx; (void)keys; (void)perm; (void)nodes;
+  pb_set_error("pb_download_lbvh: not implemented yet");
+  return PB_ERR_STATE;
+}
+
+int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh, float* d_rgb_out, void* stream) {
+  if (!ctx || !d_rgb_out || w <= 0 || h <= 0 || x0 < 0 || y0 < 0) { pb_set_error("pb_render: bad argument"); return PB_ERR_ARG; }
+  if (x0 + w > ctx->ctl.screen_width || y0 + h > ctx->ctl.screen_height) { pb_set_error("pb_render: rectangle exceeds the screen"); return PB_ERR_ARG; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  return render_common(ctx, x0, y0, w, h, 1, mode, use_lbvh, d_rgb_out, (hipStream_t)stream);
+}
+
+int pb_render(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh, float* rgb_out) {
+  if (!ctx || !rgb_out || w <= 0 || h <= 0) { pb_set_error("pb_render: bad argument"); return PB_ERR_ARG; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  size_t need = (size_t)w * h * 3;
+  if (need > ctx->out_floats) {
+    if (ctx->d_out) { PB_HIP(hipFree(ctx->d_out)); ctx->d_out = nullptr; ctx->out_floats = 0; }
+    PB_HIP(hipMalloc(&ctx->d_out, sizeof(float) * need));
+    ctx->out_floats = need;
+  }
+  rc = pb_render_d(ctx, x0, y0, w, h, mode, use_lbvh, ctx->d_out, ctx->stream);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipMemcpyAsync(rgb_out, ctx->d_out, sizeof(float) * need, hipMemcpyDeviceToHost, ctx->stream));
+  PB_HIP(hipStreamSynchronize(ctx->stream));
+  return PB_OK;
+}
+
+int pb_render_strips_d(pb_ctx* ctx, int first_strip, int strip_stride, int n_strips, int mode, int use_lbvh,
+                       float* d_rgb_out, void* stream) {
+  if (!ctx || !d_rgb_out || first_strip < 0 || strip_stride <= 0 || n_strips <= 0) { pb_set_error("pb_render_strips_d: bad argument"); return PB_ERR_ARG; }
+  const int last_y = 8 * (first_strip + (n_strips - 1) * strip_stride);
+  if (last_y >= ctx->ctl.screen_height) { pb_set_error("pb_render_strips_d: strips exceed the screen"); return PB_ERR_ARG; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  return render_common(ctx, 0, 8 * first_strip, ctx->ctl.screen_width, 8 * n_strips, strip_stride, mode, use_lbvh,
+                       d_rgb_out, (hipStream_t)stream);
+}
+
+int pb_quantise_argb(const float* rgb, int n_pixels, uint32_t* argb_out) {
+  if (!rgb || !argb_out || n_pixels < 0) { pb_set_error("pb_quantise_argb: bad argument"); return PB_ERR_ARG; }
+  for (int i = 0; i < n_pixels; ++i) {
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+      float v = 255 * rgb[3 * (size_t)i + k];
+      v = (v < 0.f) ? 0.f : v;          // glm::clamp = min(max(x, lo), hi)
+      v = (255.f < v) ? 255.f : v;
+      q[k] = (uint32_t)v;
+    }
+    argb_out[i] = (128u << 24) + (q[0] << 16) + (q[1] << 8) + q[2];
+  }
+  return PB_OK;
+}
+
+int pb_enable_counters(pb_ctx* ctx, int on) {
+  if (!ctx) { pb_set_error("pb_enable_counters: null context"); return PB_ERR_ARG; }
+  ctx->count_on = on != 0;
+  return PB_OK;
+}
+
+int pb_counters(pb_ctx* ctx, pb_stats* out) {
+  if (!ctx || !out) { pb_set_error("pb_counters: null argument"); return PB_ERR_ARG; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipDeviceSynchronize());
+  float ms = 0;
+  if (ctx->ev_valid[0]) { PB_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_render = ms; }
+  if (ctx->ev_valid[1]) { PB_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_prepare = ms; }
+  if (ctx->ev_valid[2]) { PB_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_build = ms; }
+  if (ctx->ev_valid[3]) { PB_HIP(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); ctx->stats.ms_emit = ms; }
+  unsigned long long h[PB_CNT_N];
+  PB_HIP(hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  ctx->stats.rays = h[PB_CNT_RAYS]; ctx->stats.rays_hit_scene = h[PB_CNT_RAYS_HIT];
+  ctx->stats.candidates = h[PB_CNT_CAND]; ctx->stats.cyl_hits = h[PB_CNT_CYL];
+  ctx->stats.valid_hits = h[PB_CNT_VALID]; ctx->stats.nodes_visited = h[PB_CNT_NODES];
+  *out = ctx->stats;
+  return PB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Internal device/host structures of libphoton_beams.so.
+#ifndef PB_INTERNAL_H
+#define PB_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/photon_beams.h"
+#include "pb_device_math.h"
+
+// Tessendorf.h:4 — the reference's PI.
+#define PB_PI_REF 3.14159265
+// Tessendorf.h:23
+#define PB_ACTUAL_WIDTH 2.0f
+
+// One Cornell-box triangle in camera space, with the ray-independent cofactors
+// of ClosestIntersection's inverse(mat3(-dir, e1, e2)) (Intersections.h:468-485).
+// 16 floats = 64 B, read through scalar loads (the index is wave-uniform).
+struct TriPrep {
+  float v0[3];
+  float e1[3];
+  float e2[3];
+  float c0, c1, c2;   // e1y*e2z-e2y*e1z, e1x*e2z-e2x*e1z, e1x*e2y-e2x*e1y
+  float n[3];         // Triangle::normal.xyz (TestModelH.h:29-38), world == camera for theta = 0
+  float pad;
+};
+static_assert(sizeof(TriPrep) == 64, "TriPrep layout");
+
+// Everything HitCylinder (Intersections.h:313-346) derives from a segment alone,
+// computed once per segment with the reference's operation order, plus the
+// gate box and the radiance weight.  48 dwords = 192 B, 64-byte aligned so a
+// wave-uniform record is fetched with three s_load_dwordx16.
+struct __attribute__((aligned(64))) SegFrame {
+  float Rinv[9];   //  0.. 8  R_inv, m[col][row] at col*3+row
+  float Tinv[3];   //  9..11  T_inv == origin_prime for a camera ray from (0,0,0)
+  float c4;        // 12      4*c, c of Intersections.h:344-346
+  float Sinv;      // 13      1/|end-start|
+  float tb0;       // 14      |start-orig_start|
+  float ox2, oz2;  // 15,16   2*Tinv.x, 2*Tinv.z
+  float R[9];      // 17..25  inverse(R_inv) (Intersections.h:443-444)
+  float bdir[3];   // 26..28  normalize(end-start)
+  float lo[3];     // 29..31  gate box, min_b of HitBoundingBox
+  float hi[3];     // 32..34  max_b
+  uint32_t qflags; // 35      bit i: origin inside slab i (MIDDLE); bit 3: origin inside the box
+  double W[3];     // 36..41  energy*(1/(4 PI))*(sigma_s/(PI r^2)) (721) or energy*(1/(4 PI)) (73het)
+  float cand[3];   // 42..44  candidate planes of HitBoundingBox for the origin (0,0,0)
+  float radius;    // 45
+  float pad[2];
+};
+static_assert(sizeof(SegFrame) == 192, "SegFrame layout");
+
+// Gate box of the tree root (BeamRadiance.h:426-430 applied to `root`).
+struct GateBox {
+  float lo[3], hi[3], cand[3];
+  uint32_t qflags;
+};
+
+struct RenderParams {
+  const TriPrep* tris;
+  int n_tri;
+  const SegFrame* frames;
+  const float4* capA;      // (start.xyz, radius)
+  const float4* capB;      // (end.xyz, 0)
+  int n_seg;
+  GateBox root;
+  int width, height, ssaa; // SCREEN_WIDTH, SCREEN_HEIGHT, SSAA
+  float focal;             // rasteriser.h:17
+  float extinction_c;      // Control.h:48
+  // geometry of this launch: tile (tx, k) covers pixels x = x0 + 8*tx + lx,
+  // y = y0 + 8*k*strip_stride + ly; output row = 8*k + ly, row length out_w
+  int x0, y0, out_w, out_h, strip_stride, tiles_x, tiles_y;
+  float* out;              // out_h * out_w * 3
+  unsigned long long* counters;  // 8 words or nullptr
+  // LBVH (null: scan all segments)
+  const void* lbvh_nodes;
+  const uint32_t* lbvh_perm;
+};
+
+enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_N };
+
+void pb_set_error(const std::string& msg);
+
+#define PB_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      pb_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                       \
+      return PB_ERR_DEVICE;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+// launchers implemented in the kernel translation units
+int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matrix16, TriPrep* d_out, hipStream_t s);
+int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float scattering_c, SegFrame* d_frames,
+                               float4* d_capA, float4* d_capB, hipStream_t s);
+int pb_launch_render(const RenderParams& p, int mode, bool count, hipStream_t s);
+
+#endif

@@ -1,0 +1,134 @@
+// Per-scene and per-segment precomputation.  Everything here is a function of
+// the scene or of one segment only; the reference recomputes it for every
+// (ray, triangle) and (ray, segment) pair.  The arithmetic keeps the reference's
+// operation order (file built with -ffp-contract=off), so the per-pair kernels
+// see bit-identical operands.
+#include "pb_internal.h"
+
+// ClosestIntersection, Intersections.h:468-476: v = matrix * triangle vertex,
+// e1 = v1 - v0, e2 = v2 - v0, and the cofactors of columns 1,2 of A = (-dir,e1,e2).
+__global__ void prepare_scene_kernel(const float* __restrict__ tri_xyz, int n_tri, const float* __restrict__ matrix,
+                                     TriPrep* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tri) return;
+  float m[16];
+  for (int k = 0; k < 16; ++k) m[k] = matrix[k];
+  const float* t = tri_xyz + (size_t)i * 9;
+  V4 w0 = v4(t[0], t[1], t[2], 1.0f), w1 = v4(t[3], t[4], t[5], 1.0f), w2 = v4(t[6], t[7], t[8], 1.0f);
+  V4 v0 = mul4(m, w0), v1 = mul4(m, w1), v2 = mul4(m, w2);
+  V3 e1 = v3(v1.x - v0.x, v1.y - v0.y, v1.z - v0.z);
+  V3 e2 = v3(v2.x - v0.x, v2.y - v0.y, v2.z - v0.z);
+  TriPrep p;
+  p.v0[0] = v0.x; p.v0[1] = v0.y; p.v0[2] = v0.z;
+  p.e1[0] = e1.x; p.e1[1] = e1.y; p.e1[2] = e1.z;
+  p.e2[0] = e2.x; p.e2[1] = e2.y; p.e2[2] = e2.z;
+  p.c0 = e1.y * e2.z - e2.y * e1.z;
+  p.c1 = e1.x * e2.z - e2.x * e1.z;
+  p.c2 = e1.x * e2.y - e2.x * e1.y;
+  // Triangle::ComputeNormal, TestModelH.h:29-38 (world-space vertices)
+  V3 f1 = v3(w1.x - w0.x, w1.y - w0.y, w1.z - w0.z);
+  V3 f2 = v3(w2.x - w0.x, w2.y - w0.y, w2.z - w0.z);
+  V3 n = normalize3(cross3(f2, f1));
+  p.n[0] = n.x; p.n[1] = n.y; p.n[2] = n.z;
+  p.pad = 0.0f;
+  out[i] = p;
+}
+
+// findRotationMatrix, Intersections.h:499-513.
+__device__ M3 find_rotation_matrix(V3 c_dir, V3 w_dir) {
+  V3 v = cross3(c_dir, w_dir);
+  float c = dot3(c_dir, w_dir);
+  M3 vx;
+  vx.m[0][0] = 0;    vx.m[1][0] = -v.z; vx.m[2][0] = v.y;
+  vx.m[0][1] = v.z;  vx.m[1][1] = 0;    vx.m[2][1] = -v.x;
+  vx.m[0][2] = -v.y; vx.m[1][2] = v.x;  vx.m[2][2] = 0;
+  M3 vx2 = mul(vx, vx);
+  float k = 1 / (1 + c);
+  M3 R;
+  for (int col = 0; col < 3; ++col)
+    for (int row = 0; row < 3; ++row) {
+      float id = (col == row) ? 1.0f : 0.0f;
+      R.m[col][row] = (id + vx.m[col][row]) + (vx2.m[col][row] * k);
+    }
+  return R;
+}
+
+// Candidate planes and quadrant flags of HitBoundingBox (Intersections.h:95-112)
+// for the fixed ray origin (0,0,0).
+__device__ void gate_setup(const float lo[3], const float hi[3], float cand[3], uint32_t& qflags) {
+  uint32_t q = 0;
+  bool inside = true;
+  for (int i = 0; i < 3; ++i) {
+    if (0.0f < lo[i]) { cand[i] = lo[i]; inside = false; }
+    else if (0.0f > hi[i]) { cand[i] = hi[i]; inside = false; }
+    else { cand[i] = 0.0f; q |= (1u << i); }
+  }
+  if (inside) q |= 8u;
+  qflags = q;
+}
+
+__global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int n, int mode, float scattering_c,
+                                        SegFrame* __restrict__ frames, float4* __restrict__ capA,
+                                        float4* __restrict__ capB) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const pb_segment s = segs[i];
+  V3 start = v3(s.start[0], s.start[1], s.start[2]);
+  V3 end = v3(s.end[0], s.end[1], s.end[2]);
+  V3 ostart = v3(s.orig_start[0], s.orig_start[1], s.orig_start[2]);
+  // HitCylinder, Intersections.h:313-328
+  V3 difference = end - start;
+  float len = length3(difference);
+  V3 w_unit = normalize3(v3(0.0f, len, 0.0f));
+  float Sinv = 1 / len;
+  V3 c_unit = difference * Sinv;
+  M3 Rinv = find_rotation_matrix(c_unit, w_unit);
+  V3 Tinv = -(mul(Rinv, start) * Sinv);
+  float rs = s.radius * Sinv;
+  // float + float - double, rounded to float once (Intersections.h:344-346)
+  float c = (float)((double)(Tinv.x * Tinv.x + Tinv.z * Tinv.z) - (double)rs * (double)rs);
+  M3 R = inverse3(Rinv);
+  SegFrame f;
+  for (int col = 0; col < 3; ++col)
+    for (int row = 0; row < 3; ++row) { f.Rinv[col * 3 + row] = Rinv.m[col][row]; f.R[col * 3 + row] = R.m[col][row]; }
+  f.Tinv[0] = Tinv.x; f.Tinv[1] = Tinv.y; f.Tinv[2] = Tinv.z;
+  f.c4 = 4 * c;
+  f.Sinv = Sinv;
+  // |seg.start - seg.orig_start| as a vec4 length, w = 1 - 1 = 0  (Intersections.h:440)
+  V4 d4 = v4(start.x - ostart.x, start.y - ostart.y, start.z - ostart.z, 0.0f);
+  f.tb0 = length4(d4);
+  f.ox2 = 2 * Tinv.x; f.oz2 = 2 * Tinv.z;
+  f.bdir[0] = c_unit.x; f.bdir[1] = c_unit.y; f.bdir[2] = c_unit.z;
+  for (int k = 0; k < 3; ++k) { f.lo[k] = s.cull_lo[k]; f.hi[k] = s.cull_hi[k]; }
+  gate_setup(f.lo, f.hi, f.cand, f.qflags);
+  // BeamRadiance.h:446-455 (721) / :389-397 (73het): energy * phase_f [* rad]
+  double phase_f = 1 / (4 * PB_PI_REF);
+  for (int k = 0; k < 3; ++k) {
+    double w = (double)s.energy[k] * phase_f;
+    if (mode == PB_MODE_721) {
+      double rad = (double)scattering_c / (PB_PI_REF * ((double)s.radius * (double)s.radius));
+      w = w * rad;
+    }
+    f.W[k] = w;
+  }
+  f.radius = s.radius;
+  f.pad[0] = f.pad[1] = 0.0f;
+  frames[i] = f;
+  capA[i] = make_float4(start.x, start.y, start.z, s.radius);
+  capB[i] = make_float4(end.x, end.y, end.z, 0.0f);
+}
+
+int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_matrix16, TriPrep* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(prepare_scene_kernel, dim3((n_tri + 63) / 64), dim3(64), 0, s, d_tri_xyz, n_tri, d_matrix16, d_out);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}
+
+int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float scattering_c, SegFrame* d_frames,
+                               float4* d_capA, float4* d_capB, hipStream_t s) {
+  if (n <= 0) return PB_OK;
+  hipLaunchKernelGGL(prepare_segments_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_segs, n, mode, scattering_c,
+                     d_frames, d_capA, d_capB);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}

@@ -1,0 +1,274 @@
+// DrawStandard (skeleton.cpp:330-365) on the GPU: one wavefront owns an 8x8
+// pixel tile (one camera ray per lane).  All camera rays start at (0,0,0), so
+// the rays of a tile span a thin pyramid with its apex at the origin; the wave
+// first finds, cooperatively (one segment or one LBVH node per lane), the
+// segments whose capsule can touch that pyramid, then every lane evaluates its
+// own ray against each candidate, whose per-segment record is wave-uniform
+// and therefore fetched through the scalar unit.
+//
+// Built with -ffp-contract=off: the gate (HitBoundingBox + max_distance,
+// BeamRadiance.h:426-430) is discontinuous in its inputs and is evaluated with
+// the reference's exact operation order.
+#include "pb_internal.h"
+
+namespace {
+
+struct Ray {
+  V3 l;        // normalize(vec3(dir))              Intersections.h:313, BeamRadiance.h:88
+  V3 dn;       // xyz of normalize(vec4 dir) again  Intersections.h:91
+  float maxd;  // |limit.position - start|          BeamRadiance.h:426
+  bool active;
+};
+
+// ClosestIntersection, Intersections.h:458-497, on prepared triangles.
+PB_DI bool closest_intersection(const TriPrep* __restrict__ tris, int n_tri, V4 start, V4 dir, V4& position,
+                                float& distance, int& index) {
+  bool found = false;
+  float best = 3.402823466e+38f;   // Intersections.h:57
+  int best_i = -1;
+  const float ndx = -dir.x, ndy = -dir.y, ndz = -dir.z;
+  for (int i = 0; i < n_tri; ++i) {
+    const TriPrep& T = tris[i];
+    const float bx = start.x - T.v0[0], by = start.y - T.v0[1], bz = start.z - T.v0[2];
+    const float e1x = T.e1[0], e1y = T.e1[1], e1z = T.e1[2];
+    const float e2x = T.e2[0], e2y = T.e2[1], e2z = T.e2[2];
+    const float P = ndy * e2z - e2y * ndz;
+    const float Q = ndy * e1z - e1y * ndz;
+    const float det = ndx * T.c0 - e1x * P + e2x * Q;
+    const float ood = 1.0f / det;
+    const float i00 = T.c0 * ood;
+    const float i10 = -T.c1 * ood;
+    const float i20 = T.c2 * ood;
+    const float i01 = -P * ood;
+    const float i11 = (ndx * e2z - e2x * ndz) * ood;
+    const float i21 = -(ndx * e2y - e2x * ndy) * ood;
+    const float i02 = Q * ood;
+    const float i12 = -(ndx * e1z - e1x * ndz) * ood;
+    const float i22 = (ndx * e1y - e1x * ndy) * ood;
+    const float xx = i00 * bx + i10 * by + i20 * bz;
+    const float xy = i01 * bx + i11 * by + i21 * bz;
+    const float xz = i02 * bx + i12 * by + i22 * bz;
+    if (xx >= 0 && xy >= 0 && xz >= 0 && (xy + xz) < 1) {
+      if (xx < best) { found = true; best = xx; best_i = i; }
+    }
+  }
+  distance = best;
+  index = best_i;
+  if (found) position = start + dir * best;
+  return found;
+}
+
+// HitBoundingBox (Intersections.h:81-143) for a ray from (0,0,0) followed by the
+// distance test of BeamRadiance.h:429-430.  lo/hi are min_b/max_b, cand/qflags
+// the origin-dependent part prepared per box.
+PB_DI bool box_gate(const float lo[3], const float hi[3], const float cand[3], uint32_t qflags, V3 dn, float maxd) {
+  if (qflags & 8u) return 0.0f <= maxd;   // origin inside: hit = start, distance 0
+  const float d[3] = {dn.x, dn.y, dn.z};
+  float dist[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dist[i] = (d[i] != 0 && !((qflags >> i) & 1u)) ? (cand[i] / d[i]) : -1.0f;
+  int largest = 0;
+  float dl = dist[0];
+  if (dl < dist[1]) { largest = 1; dl = dist[1]; }
+  if (dl < dist[2]) { largest = 2; dl = dist[2]; }
+  if (dl < 0) return false;
+  float pos[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (largest != i) {
+      pos[i] = dl * d[i];                       // origin[i] + ... with origin 0
+      if (pos[i] < lo[i] || pos[i] > hi[i]) return false;
+    } else pos[i] = cand[i];
+  }
+  // |hit - start| as a vec4 length with w = 1 - 1 = 0
+  const float hd = pb_sqrt((pos[0] * pos[0] + pos[1] * pos[1]) + (pos[2] * pos[2] + 0.0f));
+  return hd <= maxd;
+}
+
+// Per-pixel set-up of DrawStandard, skeleton.cpp:342-350, then the root gate.
+PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
+  Ray r;
+  const float x_dir = sx - ((p.width * p.ssaa) / (float)2);
+  const float y_dir = sy - ((p.height * p.ssaa) / (float)2);
+  const V4 dir = normalize4(v4(x_dir, y_dir, p.focal, 1.0f));
+  const V4 start = v4(0, 0, 0, 1);
+  V4 pos = v4(0, 0, 0, 0);
+  float dist; int idx;
+  r.active = closest_intersection(p.tris, p.n_tri, start, dir, pos, dist, idx);
+  r.maxd = r.active ? length4(pos - start) : -1.0f;
+  r.l = normalize3(xyz(dir));
+  r.dn = xyz(normalize4(dir));
+  return r;
+}
+
+// HitCylinder (Intersections.h:307-456) with the per-segment frame prepared,
+// the two gates, Integral_721 (BeamRadiance.h:86-110) and the accumulation of
+// BeamRadianceStandard (BeamRadiance.h:441-455).  Returns 0 = no cylinder hit,
+// 1 = discriminant >= 0 but no contribution, 2 = contributed.
+PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, const GateBox& root, float extinction, double acc[3],
+                        bool& gated) {
+  const V3 l = r.l;
+  const float dpx = f.Rinv[0] * l.x + f.Rinv[3] * l.y + f.Rinv[6] * l.z;
+  const float dpz = f.Rinv[2] * l.x + f.Rinv[5] * l.y + f.Rinv[8] * l.z;
+  const float a = dpx * dpx + dpz * dpz;
+  const float b = f.ox2 * dpx + f.oz2 * dpz;
+  const float b24ac = b * b - a * f.c4;
+  if (b24ac < 0) return 0;
+  const float sq = pb_sqrt(b24ac);
+  float t0 = (-b + sq) / (2 * a);
+  float t1 = (-b - sq) / (2 * a);
+  if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+  const float dpy = f.Rinv[1] * l.x + f.Rinv[4] * l.y + f.Rinv[7] * l.z;
+  const float ox = f.Tinv[0], oy = f.Tinv[1], oz = f.Tinv[2];
+  const float y0 = oy + t0 * dpy;
+  const float y1 = oy + t1 * dpy;
+  float thf = 0.0f, ths = 0.0f;
+  bool have_second = false;
+  if (y0 < 0) {
+    if (y1 < 0) return 1;
+    thf = t0 + (t1 - t0) * y0 / (y0 - y1);
+    if (thf <= 0) return 1;
+    if (y1 <= 1) { ths = t1; have_second = true; }
+    else { float th2 = t1 + (t1 - t0) * (y1 - 1) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
+  } else if (y0 >= 0 && y0 <= 1) {
+    if (t0 <= 0) return 1;
+    thf = t0;
+    if (y1 >= 0) {
+      if (y1 <= 1) { ths = t1; have_second = true; }
+      else { float th2 = t1 + (t1 - t0) * (y1 - 1) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
+    } else { float th2 = t0 + (t1 - t0) * (y0) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
+  } else if (y0 > 1) {
+    if (y1 > 1) return 1;
+    thf = t0 + (t1 - t0) * (y0 - 1) / (y0 - y1);
+    if (thf <= 0) return 1;
+    if (y1 >= 0) { ths = t1; have_second = true; }
+    else { float th2 = t0 + (t1 - t0) * (y0) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
+  } else return 1;
+  if (!((t0 > 0) && (t1 > 0) && (t1 > t0))) return 1;
+  // the two gates of the traversal: tree root, then the segment's own gate box
+  if (!box_gate(root.lo, root.hi, root.cand, root.qflags, r.dn, r.maxd)) return 1;
+  if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
+  gated = true;
+  const float fx = ox + dpx * thf, fy = oy + dpy * thf, fz = oz + dpz * thf;
+  // second_hit is unset in the reference when no branch assigned it; that never
+  // coincides with valid == true, (0,0,0) stands in as in the CPU restatement
+  const float sx = have_second ? ox + dpx * ths : 0.0f;
+  const float sy = have_second ? oy + dpy * ths : 0.0f;
+  const float sz = have_second ? oz + dpz * ths : 0.0f;
+  const float tb_a = f.tb0 + (fy / f.Sinv);
+  const float tb_b = f.tb0 + (sy / f.Sinv);
+  const float tb_minus = fminf(tb_a, tb_b);
+  const float ux = fx - ox, uy = fy - oy, uz = fz - oz;
+  const float ex = (f.R[0] * ux + f.R[3] * uy + f.R[6] * uz) / f.Sinv;
+  const float ey = (f.R[1] * ux + f.R[4] * uy + f.R[7] * uz) / f.Sinv;
+  const float ez = (f.R[2] * ux + f.R[5] * uy + f.R[8] * uz) / f.Sinv;
+  const float wx = sx - ox, wy = sy - oy, wz = sz - oz;
+  const float qx = (f.R[0] * wx + f.R[3] * wy + f.R[6] * wz) / f.Sinv;
+  const float qy = (f.R[1] * wx + f.R[4] * wy + f.R[7] * wz) / f.Sinv;
+  const float qz = (f.R[2] * wx + f.R[5] * wy + f.R[8] * wz) / f.Sinv;
+  const float tc_minus = pb_sqrt(ex * ex + ey * ey + ez * ez);
+  const float tc_plus = pb_sqrt(qx * qx + qy * qy + qz * qz);
+  // Integral_721: float products and float exp, widened for the quotient
+  const float cos_theta = f.bdir[0] * (-l.x) + f.bdir[1] * (-l.y) + f.bdir[2] * (-l.z);
+  const float cm1 = fabsf(cos_theta) - 1;
+  const float num = expf(-extinction * (tc_minus - tc_plus) * cm1) - 1;
+  const float den = expf(extinction * (tc_minus + tb_minus)) * extinction * cm1;
+  const double integral = (double)num / (double)den;
+  acc[0] = acc[0] + f.W[0] * integral;
+  acc[1] = acc[1] + f.W[1] * integral;
+  acc[2] = acc[2] + f.W[2] * integral;
+  return 2;
+}
+
+// Conservative test: can the capsule (a, b, radius) touch the pyramid of the tile?
+// pl[k] are the four inward unit normals of the side planes (through the origin).
+PB_DI bool capsule_touches_pyramid(const float4 A, const float4 B, const V3 pl[4]) {
+  const float slack = A.w * 1.001f + 1e-5f;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float da = pl[k].x * A.x + pl[k].y * A.y + pl[k].z * A.z;
+    const float db = pl[k].x * B.x + pl[k].y * B.y + pl[k].z * B.z;
+    ok = ok && (fmaxf(da, db) >= -slack);
+  }
+  return ok;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void render_tiles_721_kernel(const RenderParams p) {
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
+  const int lx = lane & 7, ly = lane >> 3;
+  const int ox = 8 * tx + lx, oy = 8 * tk + ly;             // output coordinates
+  const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + ly;
+  const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
+  double acc[3] = {0.0, 0.0, 0.0};
+  unsigned long long c_rays = 0, c_hit = 0, c_cand = 0, c_cyl = 0, c_valid = 0, c_gated = 0;
+
+  for (int si = 0; si < p.ssaa; ++si)
+    for (int sj = 0; sj < p.ssaa; ++sj) {
+      Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
+      r.active = r.active && in_image;
+      if (COUNT) { c_rays += in_image ? 1 : 0; c_hit += r.active ? 1 : 0; }
+      if (!r.active) r.maxd = -1.0f;     // every gate fails
+      if (__ballot(r.active) == 0ull) continue;
+      // side planes of the tile pyramid in sub-ray coordinates (wave-uniform)
+      const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
+      const float xl = (float)((p.x0 + 8 * tx) * p.ssaa) - half_w - 0.5f;
+      const float xr = (float)((p.x0 + 8 * tx + 7) * p.ssaa + p.ssaa - 1) - half_w + 0.5f;
+      const int ty0 = p.y0 + 8 * tk * p.strip_stride;
+      const float yt = (float)(ty0 * p.ssaa) - half_h - 0.5f;
+      const float yb = (float)((ty0 + 7) * p.ssaa + p.ssaa - 1) - half_h + 0.5f;
+      V3 pl[4];
+      pl[0] = normalize3(v3(p.focal, 0.0f, -xl));    // x/z >= xl/focal
+      pl[1] = normalize3(v3(-p.focal, 0.0f, xr));    // x/z <= xr/focal
+      pl[2] = normalize3(v3(0.0f, p.focal, -yt));
+      pl[3] = normalize3(v3(0.0f, -p.focal, yb));
+
+      for (int base = 0; base < p.n_seg; base += 64) {
+        const int s = base + lane;
+        bool touch = false;
+        if (s < p.n_seg) touch = capsule_touches_pyramid(p.capA[s], p.capB[s], pl);
+        unsigned long long mask = __ballot(touch);
+        while (mask) {
+          const int bit = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const int sidx = __builtin_amdgcn_readfirstlane(base + bit);
+          const SegFrame& f = p.frames[sidx];
+          bool gated = false;
+          const int res = eval_pair_721(f, r, p.root, p.extinction_c, acc, gated);
+          if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; c_gated += gated ? 1 : 0; }
+        }
+      }
+    }
+
+  if (in_image) {
+    float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
+    const double inv = (double)p.ssaa;
+    o[0] = (float)(acc[0] / inv);
+    o[1] = (float)(acc[1] / inv);
+    o[2] = (float)(acc[2] / inv);
+  }
+  if (COUNT) {
+    unsigned long long v[6] = {c_rays, c_hit, c_cand, c_cyl, c_valid, c_gated};
+    const int slot[6] = {PB_CNT_RAYS, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_GATED};
+    for (int k = 0; k < 6; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
+    }
+  }
+}
+
+}  // namespace
+
+int pb_launch_render(const RenderParams& p, int mode, bool count, hipStream_t s) {
+  if (mode != PB_MODE_721) { pb_set_error("pb_render: only PB_MODE_721 is implemented"); return PB_ERR_ARG; }
+  const int tiles = p.tiles_x * p.tiles_y;
+  if (tiles <= 0) return PB_OK;
+  if (count) hipLaunchKernelGGL(render_tiles_721_kernel<true>, dim3(tiles), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(render_tiles_721_kernel<false>, dim3(tiles), dim3(64), 0, s, p);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}

@@ -1,0 +1,107 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle and the
+reference's committed render.  Tolerances are those stated for the radiance path:
+max-abs <= 2e-3 * max(1, |ref|) and RMSE <= 1e-4 per channel on pre-quantisation radiance,
+<= 1 LSB on >= 99.9 % of pixels on the 8-bit image."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pb():
+    import raytracer_amd as pb
+    if pb.device_count() < 1:
+        pytest.fail("no GPU visible: the HIP path cannot run (there is no CPU fallback)")
+    return pb
+
+
+@pytest.fixture(scope="module")
+def cfg1():
+    o = orc.Oracle()
+    o.cast_photon_beams(); o.bound_photon_beams(); o.build_tree()
+    return o
+
+
+def check_radiance(gpu, ref, what):
+    gpu = gpu.astype(np.float64)
+    tol = 2e-3 * np.maximum(1.0, np.abs(ref))
+    err = np.abs(gpu - ref)
+    assert (err <= tol).all(), f"{what}: max-abs error {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    rmse = np.sqrt((err ** 2).mean(axis=(0, 1)))
+    assert (rmse <= 1e-4).all(), f"{what}: RMSE per channel {rmse}"
+    return err.max(), rmse.max()
+
+
+def test_config1_tree_segments_full_frame(pb, cfg1, golden_dir):
+    """Configuration 1 (512^2, 1000 photons, SEED 42): the 987 tree segments with their leaf-node
+    gate boxes; GPU radiance vs oracle, and the quantised image vs the reference's screenshot."""
+    from PIL import Image
+    segs = cfg1.export_segments(tree=True)
+    lo, hi = cfg1.root_box()
+    tri, _ = orc.load_test_model()
+    ref, _ = orc.render_segments(cfg1.control, orc.tri_xyz(tri), orc.transformation_matrix(), segs, lo, hi,
+                                 0, 0, 512, 512)
+    with pb.Context(pb.control_defaults()) as ctx:
+        ctx.set_scene()
+        ctx.upload_segments(segs, lo, hi)
+        img = ctx.draw()
+        ctx.enable_counters(True)
+        ctx.draw()
+        cnt = ctx.counters()
+    maxerr, rmse = check_radiance(img, ref, "config 1")
+    print(f"config 1: max-abs {maxerr:.3e} rmse {rmse:.3e} counters {cnt}")
+    assert cnt["rays"] == 262144 and cnt["rays_hit_scene"] == 262052
+    assert cnt["valid_hits"] == 3144103          # the reference traversal's valid beam hits
+    argb = pb.quantise_argb(img)
+    shot = np.array(Image.open(os.path.join(golden_dir, "reference_screenshot.png")).convert("RGBA")).astype(np.int32)
+    mine = np.stack([(argb >> 16) & 255, (argb >> 8) & 255, argb & 255], -1).astype(np.int32)
+    d = np.abs(mine - shot[..., :3]).max(-1)
+    assert d.max() <= 1 and (d > 0).mean() <= 1e-3, (d.max(), int((d > 0).sum()))
+
+
+def test_scene_setup_matches_oracle(pb):
+    tri, nrm = pb.load_test_model()
+    otri, onrm = orc.load_test_model()
+    assert np.array_equal(tri, orc.tri_xyz(otri))
+    assert np.array_equal(nrm, onrm[:, :3])
+    assert np.array_equal(pb.transformation_matrix(), orc.transformation_matrix())
+
+
+def test_ragged_rectangles_and_strips(pb, cfg1):
+    """Rectangles that are not multiples of the 8x8 tile, a 1x1 rectangle, and interleaved strips."""
+    import torch
+    segs = cfg1.export_segments(tree=True)
+    lo, hi = cfg1.root_box()
+    with pb.Context(pb.control_defaults()) as ctx:
+        ctx.set_scene()
+        ctx.upload_segments(segs, lo, hi)
+        full = ctx.draw()
+        for (x0, y0, w, h) in [(250, 90, 13, 5), (0, 0, 1, 1), (505, 500, 7, 12), (256, 93, 9, 1)]:
+            part = ctx.draw(x0, y0, w, h)
+            assert np.array_equal(part, full[y0:y0 + h, x0:x0 + w]), (x0, y0, w, h)
+        out = torch.zeros((8 * 16, 512, 3), dtype=torch.float32, device="cuda")
+        ctx.draw_strips_device(out.data_ptr(), 3, 4, 16, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for k in range(16):
+            y = 8 * (3 + 4 * k)
+            assert np.array_equal(got[8 * k:8 * k + 8], full[y:y + 8]), k
+
+
+def test_empty_segment_set_and_errors(pb):
+    with pb.Context(pb.control_defaults(screen_width=64, screen_height=64)) as ctx:
+        with pytest.raises(pb.PhotonBeamsError):
+            ctx.draw()                               # no scene yet
+        ctx.set_scene()
+        with pytest.raises(pb.PhotonBeamsError):
+            ctx.draw()                               # no segments yet
+        ctx.upload_segments(np.zeros(0, pb.SEGMENT_DTYPE), [-1, -1, 1], [1, 1, 4])
+        img = ctx.draw()
+        assert img.shape == (64, 64, 3) and not img.any()
+        with pytest.raises(pb.PhotonBeamsError):
+            ctx.draw(0, 0, 65, 1)                    # rectangle exceeds the screen
