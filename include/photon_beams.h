@@ -107,6 +107,10 @@ typedef struct pb_stats {
   uint64_t cyl_hits;         /* pairs with a non-negative discriminant            */
   uint64_t valid_hits;       /* pairs that contributed radiance                   */
   uint64_t nodes_visited;    /* LBVH nodes tested by the tile traversal           */
+  uint64_t gate_passes;      /* (ray, segment) pairs whose root and gate boxes are
+                                entered within the surface distance: the pairs on
+                                which the reference calls HitCylinder
+                                (BeamRadiance.h:428-439); counted by a full scan   */
   float ms_render;           /* device time of the last pb_render (HIP events)    */
   float ms_build;            /* device time of the last pb_build_lbvh             */
   float ms_prepare;          /* device time of the last segment upload/prepare    */
@@ -164,7 +168,8 @@ int pb_get_root_box(pb_ctx* ctx, float root_lo[3], float root_hi[3]);
  * (seed, photon, draw), beams pushed in (photon, order) order.  The result
  * replaces the context's segment set (own-box cull rule) and root box. */
 int pb_emit_beams(pb_ctx* ctx, int n_photons, uint64_t seed, int* n_beams_out, int* n_segments_out);
-int pb_download_beams(pb_ctx* ctx, pb_beam* out, int capacity, int* n_out);
+int pb_download_beams(pb_ctx* ctx, pb_beam* out, int capacity, int* n_out);  /* const list, then scattered list */
+int pb_beam_counts(pb_ctx* ctx, int* n_const, int* n_scattered);
 
 /* BuildTree (CastPhotons.h:800-1126) replacement: Morton codes of the segment
  * midpoints, LDS radix sort, Karras hierarchy, bottom-up refit. */

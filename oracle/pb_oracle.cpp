@@ -1325,10 +1325,24 @@ int orc_render_tree(orc_ctx* c, int x0, int y0, int w, int h, int mode, double* 
   return 0;
 }
 
+int orc_render_segments_strided(const pb_control* control, const float* tri_xyz, int n_tri, const float m16[16],
+                                const float* grid_sigma, int side, const pb_segment* segs, int n,
+                                const float root_lo[3], const float root_hi[3], int x0, int y0, int w, int h,
+                                int step_x, int step_y, int mode, double* rgb, orc_counters* counters, int threads);
+
 int orc_render_segments(const pb_control* control, const float* tri_xyz, int n_tri, const float m16[16],
                         const float* grid_sigma, int side, const pb_segment* segs, int n, const float root_lo[3],
                         const float root_hi[3], int x0, int y0, int w, int h, int mode, double* rgb,
                         orc_counters* counters, int threads) {
+  return orc_render_segments_strided(control, tri_xyz, n_tri, m16, grid_sigma, side, segs, n, root_lo, root_hi, x0, y0,
+                                     w, h, 1, 1, mode, rgb, counters, threads);
+}
+
+// Same estimate on the pixel lattice (x0 + i*step_x, y0 + j*step_y), i < w, j < h.
+int orc_render_segments_strided(const pb_control* control, const float* tri_xyz, int n_tri, const float m16[16],
+                                const float* grid_sigma, int side, const pb_segment* segs, int n,
+                                const float root_lo[3], const float root_hi[3], int x0, int y0, int w, int h,
+                                int step_x, int step_y, int mode, double* rgb, orc_counters* counters, int threads) {
   Control ctl; ctl.c = *control;
   std::vector<Triangle> tris = tris_from_xyz(tri_xyz, n_tri);
   mat4 M; std::memcpy(M.m, m16, sizeof(float) * 16);
@@ -1359,7 +1373,7 @@ int orc_render_segments(const pb_control* control, const float* tri_xyz, int n_t
           for (int j = 0; j < ssaa; ++j) {
             RayCtx r;
             cnt.rays++;
-            if (!camera_ray(ctl, tris, M, (x0 + xx) * ssaa + i, (y0 + yy) * ssaa + j, r)) continue;
+            if (!camera_ray(ctl, tris, M, (x0 + xx * step_x) * ssaa + i, (y0 + yy * step_y) * ssaa + j, r)) continue;
             cnt.rays_hit_scene++;
             cnt.node_visits++;
             if (!box_gate(root, r)) continue;

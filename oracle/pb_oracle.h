@@ -75,6 +75,10 @@ int  orc_render_segments(const pb_control* control, const float* tri_xyz /*n*9 w
                          const pb_segment* segs, int n, const float root_lo[3], const float root_hi[3],
                          int x0, int y0, int w, int h, int mode, double* rgb, orc_counters* counters,
                          int threads);
+int  orc_render_segments_strided(const pb_control* control, const float* tri_xyz, int n_tri, const float m16[16],
+                         const float* grid_sigma, int side, const pb_segment* segs, int n,
+                         const float root_lo[3], const float root_hi[3], int x0, int y0, int w, int h,
+                         int step_x, int step_y, int mode, double* rgb, orc_counters* counters, int threads);
 int  orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@ class Control(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rays_hit_scene", C.c_uint64), ("candidates", C.c_uint64),
-                ("cyl_hits", C.c_uint64), ("valid_hits", C.c_uint64), ("nodes_visited", C.c_uint64),
+                ("cyl_hits", C.c_uint64), ("valid_hits", C.c_uint64), ("nodes_visited", C.c_uint64), ("gate_passes", C.c_uint64),
                 ("ms_render", C.c_float), ("ms_build", C.c_float), ("ms_prepare", C.c_float),
                 ("ms_emit", C.c_float)]
 
@@ -247,7 +247,14 @@ class Context:
         _check(self.L.pb_emit_beams(self.h, C.c_int(n), C.c_uint64(seed), C.byref(nb), C.byref(ns)), "pb_emit_beams")
         return nb.value, ns.value
 
-    def download_beams(self, capacity):
+    def beam_counts(self):
+        a = C.c_int(0); b = C.c_int(0)
+        _check(self.L.pb_beam_counts(self.h, C.byref(a), C.byref(b)), "pb_beam_counts")
+        return a.value, b.value
+
+    def download_beams(self, capacity=None):
+        if capacity is None:
+            capacity = max(sum(self.beam_counts()), 1)
         out = np.zeros(capacity, BEAM_DTYPE)
         got = C.c_int(0)
         _check(self.L.pb_download_beams(self.h, out.ctypes.data_as(C.c_void_p), C.c_int(capacity), C.byref(got)),

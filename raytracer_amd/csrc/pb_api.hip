@@ -10,35 +10,6 @@
 static thread_local std::string g_last_error;
 void pb_set_error(const std::string& msg) { g_last_error = msg; }
 
-struct pb_ctx {
-  pb_control ctl;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[8] = {};   // pairs: 0,1 render; 2,3 prepare; 4,5 build; 6,7 emit
-  bool ev_valid[4] = {false, false, false, false};
-  // scene
-  float* d_tri_xyz = nullptr;
-  float* d_matrix = nullptr;
-  TriPrep* d_tris = nullptr;
-  int n_tri = 0;
-  float matrix[16];
-  // segments
-  pb_segment* d_segs = nullptr;
-  SegFrame* d_frames = nullptr;
-  float4* d_capA = nullptr;
-  float4* d_capB = nullptr;
-  int n_seg = 0, cap_seg = 0, frame_mode = 0;
-  bool have_segments = false;
-  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
-  // output staging for the host-pointer render
-  float* d_out = nullptr;
-  size_t out_floats = 0;
-  // counters
-  unsigned long long* d_counters = nullptr;
-  bool count_on = false;
-  pb_stats stats;
-};
-
 namespace {
 
 int ensure_device(pb_ctx* ctx) {
@@ -61,7 +32,9 @@ void host_gate_setup(const float lo[3], const float hi[3], GateBox& g) {
   g.qflags = q;
 }
 
-int ensure_segment_capacity(pb_ctx* ctx, int n) {
+}  // namespace
+
+int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
   if (n <= ctx->cap_seg) return PB_OK;
   int cap = n + n / 8 + 64;
   if (ctx->d_segs) PB_HIP(hipFree(ctx->d_segs));
@@ -77,11 +50,15 @@ int ensure_segment_capacity(pb_ctx* ctx, int n) {
   return PB_OK;
 }
 
+namespace {
+
 int default_mode(const pb_ctx* ctx) {
   return (ctx->ctl.heterogeneous && ctx->ctl.one_dimensional) ? PB_MODE_73HET : PB_MODE_721;
 }
 
-int prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
+}  // namespace
+
+int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
   PB_HIP(hipEventRecord(ctx->ev[2], s));
   int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA,
                                       ctx->d_capB, s);
@@ -92,6 +69,10 @@ int prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
   return PB_OK;
 }
 
+int pb_default_mode(const pb_ctx* ctx) { return default_mode(ctx); }
+
+namespace {
+
 int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_stride, int mode, int use_lbvh,
                   float* d_out, hipStream_t s) {
   if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
@@ -99,7 +80,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   if (mode != PB_MODE_721 && mode != PB_MODE_73HET) { pb_set_error("pb_render: mode must be PB_MODE_721 or PB_MODE_73HET"); return PB_ERR_ARG; }
   if (use_lbvh) { pb_set_error("pb_render: pb_build_lbvh has not been called"); return PB_ERR_STATE; }
   if (ctx->frame_mode != mode) {
-    int rc = prepare_frames(ctx, mode, s);
+    int rc = pb_prepare_frames(ctx, mode, s);
     if (rc != PB_OK) return rc;
   }
   RenderParams p;
@@ -178,7 +159,7 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
-                  ctx->d_out, ctx->d_counters};
+                  ctx->d_out, ctx->d_counters, ctx->d_beams};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -225,14 +206,14 @@ static int upload_common(pb_ctx* ctx, const pb_segment* src, bool src_on_device,
   if (!ctx || (!src && n > 0) || n < 0 || !root_lo || !root_hi) { pb_set_error("pb_upload_segments: bad argument"); return PB_ERR_ARG; }
   int rc = ensure_device(ctx);
   if (rc != PB_OK) return rc;
-  rc = ensure_segment_capacity(ctx, n);
+  rc = pb_ensure_segment_capacity(ctx, n);
   if (rc != PB_OK) return rc;
   if (n > 0)
     PB_HIP(hipMemcpyAsync(ctx->d_segs, src, sizeof(pb_segment) * (size_t)n,
                           src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   ctx->n_seg = n;
   for (int k = 0; k < 3; ++k) { ctx->root_lo[k] = root_lo[k]; ctx->root_hi[k] = root_hi[k]; }
-  rc = prepare_frames(ctx, default_mode(ctx), s);
+  rc = pb_prepare_frames(ctx, default_mode(ctx), s);
   if (rc != PB_OK) return rc;
   ctx->have_segments = true;
   return PB_OK;
@@ -277,15 +258,36 @@ int pb_get_root_box(pb_ctx* ctx, float root_lo[3], float root_hi[3]) {
 }
 
 int pb_emit_beams(pb_ctx* ctx, int n_photons, uint64_t seed, int* n_beams_out, int* n_segments_out) {
-  (void)ctx; (void)n_photons; (void)seed; (void)n_beams_out; (void)n_segments_out;
-  pb_set_error("pb_emit_beams: GPU emission is not implemented yet");
-  return PB_ERR_STATE;
+  if (!ctx || n_photons < 0) { pb_set_error("pb_emit_beams: bad argument"); return PB_ERR_ARG; }
+  if (!ctx->d_tris) { pb_set_error("pb_emit_beams: pb_set_scene has not been called"); return PB_ERR_STATE; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  rc = pb_emit_run(ctx, n_photons, seed);
+  if (rc != PB_OK) return rc;
+  if (n_beams_out) *n_beams_out = ctx->n_beams_const + ctx->n_beams_scatt;
+  if (n_segments_out) *n_segments_out = ctx->n_seg;
+  return PB_OK;
 }
+
 int pb_download_beams(pb_ctx* ctx, pb_beam* out, int capacity, int* n_out) {
-  (void)ctx; (void)out; (void)capacity; (void)n_out;
-  pb_set_error("pb_download_beams: GPU emission is not implemented yet");
-  return PB_ERR_STATE;
+  if (!ctx || !out || !n_out) { pb_set_error("pb_download_beams: null argument"); return PB_ERR_ARG; }
+  const int n = ctx->n_beams_const + ctx->n_beams_scatt;
+  if (!ctx->d_beams && n > 0) { pb_set_error("pb_download_beams: pb_emit_beams has not been called"); return PB_ERR_STATE; }
+  if (capacity < n) { pb_set_error("pb_download_beams: output array too small"); return PB_ERR_CAPACITY; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipDeviceSynchronize());
+  if (n > 0) PB_HIP(hipMemcpy(out, ctx->d_beams, sizeof(pb_beam) * (size_t)n, hipMemcpyDeviceToHost));
+  *n_out = n;
+  return PB_OK;
 }
+
+int pb_beam_counts(pb_ctx* ctx, int* n_const, int* n_scatt) {
+  if (!ctx || !n_const || !n_scatt) { pb_set_error("pb_beam_counts: null argument"); return PB_ERR_ARG; }
+  *n_const = ctx->n_beams_const; *n_scatt = ctx->n_beams_scatt;
+  return PB_OK;
+}
+
 int pb_build_lbvh(pb_ctx* ctx) {
   (void)ctx;
   pb_set_error("pb_build_lbvh: not implemented yet");
@@ -369,6 +371,7 @@ int pb_counters(pb_ctx* ctx, pb_stats* out) {
   ctx->stats.rays = h[PB_CNT_RAYS]; ctx->stats.rays_hit_scene = h[PB_CNT_RAYS_HIT];
   ctx->stats.candidates = h[PB_CNT_CAND]; ctx->stats.cyl_hits = h[PB_CNT_CYL];
   ctx->stats.valid_hits = h[PB_CNT_VALID]; ctx->stats.nodes_visited = h[PB_CNT_NODES];
+  ctx->stats.gate_passes = h[PB_CNT_GATED];
   *out = ctx->stats;
   return PB_OK;
 }

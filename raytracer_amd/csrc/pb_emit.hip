@@ -1,0 +1,525 @@
+// CastPhotonBeams / CastBeam / FindDirection (CastPhotons.h:312-633, :1128-1141)
+// and BoundPhotonBeams (CastPhotons.h:144-288) on the GPU.
+//
+// One lane per photon.  The reference draws from one sequential std::mt19937;
+// here draw k of photon p is philox4x32-10(counter = (p, k, 0, 0), key = seed),
+// consumed in the reference's order (its recursion is walked depth-first with
+// an explicit stack), so the photon streams are independent and the result does
+// not depend on the launch geometry.  Beams and segments are written at offsets
+// obtained from prefix sums of per-photon / per-beam counts, i.e. in the order
+// the reference's sequential push_back would give: every kernel runs twice,
+// first counting, then writing.
+#include <cstring>
+
+#include "pb_internal.h"
+#include "pb_geom.h"
+#include "pb_scan.h"
+
+namespace {
+
+constexpr int EMIT_THREADS = 64;
+constexpr int MAX_STACK = 8;   // nesting of in-medium scattering events kept per photon
+
+PB_DI void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+struct Rng {
+  uint32_t photon, draw, k0, k1;
+  PB_DI double canonical() {
+    uint32_t c[4] = {photon, draw++, 0u, 0u};
+    philox4x32_10(c, k0, k1);
+    const uint64_t hi = c[0] >> 5, lo = c[1] >> 6;
+    return (double)((hi << 26) | lo) * (1.0 / 9007199254740992.0);
+  }
+  PB_DI double range(double a, double b) { return canonical() * (b - a) + a; }
+  PB_DI double uniform() { return range(0.0, 1.0); }                           // CastPhotons.h:87
+  PB_DI double uniform_offset() { return range(-0.01, 0.01); }                 // :88
+  PB_DI double uniform_radius() { return range(0.0, 0.05); }                   // :89
+  PB_DI double uniform_beam() { return range((double)0.02f, (double)0.03f); }  // :90
+  PB_DI double uniform_small() { return range((double)0.02f, (double)0.06f); } // :91
+};
+
+struct EmitParams {
+  const TriPrep* tris;
+  int n_tri;
+  float matrix[16];
+  pb_control ctl;
+  uint64_t seed;
+  int n_photons;
+  uint32_t* cnt_const;        // counting pass: pushes of each photon into the two lists
+  uint32_t* cnt_scatt;
+  const uint32_t* off_const;  // writing pass: where the photon's pushes start
+  const uint32_t* off_scatt;
+  pb_beam* beams_const;
+  pb_beam* beams_scatt;
+  unsigned int* dropped;      // scattering events dropped because the stack was full
+};
+
+// CastPhotons.h:1128-1141
+PB_DI V4 find_direction(Rng& rng, V4 origin, V4 centre) {
+  const float r1 = (float)rng.uniform();
+  const float r2 = (float)rng.uniform();
+  const float the = (float)(2 * PB_PI_REF * r1);
+  const float phi = sqrtf(r2);
+  const float x = centre.x + (phi * cosf(the));
+  const float z = centre.z + (phi * sinf(the));
+  const float y = centre.y + sqrtf(1 - r2);
+  return v4(x, y, z, 1.0f) - origin;
+}
+
+// CastPhotons.h:635-647
+PB_DI bool intersect_plane(V3 n, V3 p0, V3 l0, V3 l, float& t) {
+  const float denom = dot3(n, l);
+  if (fabsf(denom) > 1e-6) {
+    const V3 p0l0 = p0 - l0;
+    t = dot3(p0l0, n) / denom;
+    return t >= 0;
+  }
+  return false;
+}
+
+// CastPhotons.h:1143-1146
+PB_DI double transmittance(double length, double ext) { return exp(-ext * length); }
+
+struct Frame {
+  V4 origin, direction, hit_pos;
+  V3 energy;
+  float t_s, scattered, avg_ext;
+  int bounce, parity, stage, hit_index;
+  bool hit, scatt, ada;
+};
+
+struct BeamSink {
+  const EmitParams* p;
+  uint32_t photon, order, n_const, n_scatt, off_const, off_scatt;
+};
+
+template <bool WRITE>
+PB_DI void push_beam(BeamSink& sink, int parity, V4 start, V4 end, V4 omega_u, float radius, V3 energy,
+                     int index_hit, bool ada, bool absorbed) {
+  if (WRITE) {
+    pb_beam b;
+    b.start[0] = start.x; b.start[1] = start.y; b.start[2] = start.z; b.start[3] = start.w;
+    b.end[0] = end.x; b.end[1] = end.y; b.end[2] = end.z; b.end[3] = end.w;
+    b.omega_u[0] = omega_u.x; b.omega_u[1] = omega_u.y; b.omega_u[2] = omega_u.z; b.omega_u[3] = omega_u.w;
+    b.radius = radius;
+    b.energy[0] = energy.x; b.energy[1] = energy.y; b.energy[2] = energy.z;
+    b.index_hit = index_hit;
+    b.flags = (ada ? 1u : 0u) | (absorbed ? 4u : 0u) | (parity ? 8u : 0u);   // scattered is never set (CastPhotons.h:398)
+    b.photon = sink.photon;
+    b.order = sink.order;
+    if (parity) sink.p->beams_scatt[sink.off_scatt + sink.n_scatt] = b;
+    else sink.p->beams_const[sink.off_const + sink.n_const] = b;
+  }
+  sink.order++;
+  if (parity) sink.n_scatt++; else sink.n_const++;
+}
+
+// The recursion of CastBeam (CastPhotons.h:392-633) as an explicit depth-first
+// walk: a frame is visited at stage 0 (entry up to the optional scattered
+// child) and at stage 1 (push of its own beam, then the bounce as a tail call).
+template <bool WRITE>
+PB_DI void cast_beam(const EmitParams& p, Rng& rng, BeamSink& sink, Frame first, V4 omega_u, float radius) {
+  const pb_control& C = p.ctl;
+  const float extinction_c = C.absorption_c + C.scattering_c;   // Control.h:48
+  Frame st[MAX_STACK];
+  int sp = 0;
+  st[0] = first;
+  while (sp >= 0) {
+    Frame& F = st[sp];
+    if (F.stage == 0) {
+      V4 pos = v4(0, 0, 0, 0);
+      float dist; int idx;
+      const bool hit = closest_intersection(p.tris, p.n_tri, F.origin, F.direction, pos, dist, idx);
+      float t_s;
+      if (hit) {
+        t_s = length3(xyz(pos) - xyz(F.origin));
+        if (t_s < 0.0005) { sp--; continue; }
+      } else t_s = PB_ACTUAL_WIDTH;
+      const float average_extinction = extinction_c;   // homogeneous medium (CastPhotons.h:414)
+      const float scattered = (float)rng.uniform();
+      bool scatt = false, spawn = false;
+      Frame child;
+      if ((scattered <= (C.scattering_c / extinction_c)) && C.scatter) {
+        const float tmp_t_s = (float)(-(log(1 - rng.uniform()) / average_extinction));
+        if ((tmp_t_s < t_s) && (tmp_t_s > 0)) {
+          t_s = tmp_t_s;
+          V4 start = F.origin + (t_s * normalize4(F.direction));
+          start.w = 1;
+          const float the = (float)(2 * PB_PI_REF * rng.uniform());
+          const float phi = (float)acos(1 - 2 * rng.uniform());
+          const float x = sinf(phi) * cosf(the);
+          const float y = sinf(phi) * sinf(the);
+          const float z = cosf(phi);
+          const V3 dir = normalize3(v3(x, y, z));
+          const float transmitted = (float)transmittance(t_s, average_extinction);
+          V3 ne = F.energy * transmitted;
+          if (!(ne.x == 0 && ne.y == 0 && ne.z == 0)) {
+            ne.x = fminf(F.energy.x, fmaxf(ne.x, 0.f));
+            ne.y = fminf(F.energy.y, fmaxf(ne.y, 0.f));
+            ne.z = fminf(F.energy.z, fmaxf(ne.z, 0.f));
+            child.origin = start;
+            child.direction = v4(dir.x, dir.y, dir.z, 1.0f);
+            child.energy = ne;
+            child.bounce = F.bounce;
+            child.parity = F.parity ^ 1;   // add_to and other swap (CastPhotons.h:458-460)
+            child.stage = 0;
+            child.ada = false;
+            spawn = true;
+          }
+          if (C.short_beams) scatt = true;
+        }
+      } else {
+        const float tmp_t_s = (float)(-(log(1 - rng.uniform()) / average_extinction));
+        if ((tmp_t_s < t_s) && (tmp_t_s > 0)) { sp--; continue; }   // absorbed in flight, never pushed (:469-479)
+      }
+      F.t_s = t_s; F.scattered = scattered; F.avg_ext = average_extinction;
+      F.hit = hit; F.hit_pos = pos; F.hit_index = idx; F.scatt = scatt;
+      F.stage = 1;
+      if (spawn) {
+        if (sp + 1 < MAX_STACK) { st[++sp] = child; continue; }
+        atomicAdd(p.dropped, 1u);
+      }
+    }
+    // stage 1: the second ClosestIntersection of the reference has the same
+    // arguments as the first, its result is the stored one
+    const V4 origin = F.origin, direction = F.direction;
+    const V3 energy = F.energy;
+    if (F.hit) {
+      V4 end;
+      if (F.scatt) { end = origin + (F.t_s * direction); end.w = 1.0f; }
+      else end = F.hit_pos;
+      const float absorbed = (float)rng.uniform();
+      const bool is_absorbed = absorbed < C.absorbed;
+      push_beam<WRITE>(sink, F.parity, origin, end, omega_u, radius, energy, F.hit_index, F.ada, is_absorbed);
+      if ((F.bounce < C.bounces) && (!is_absorbed) && (!F.scatt)) {
+        const TriPrep& T = p.tris[F.hit_index];
+        const V4 normal = v4(T.n[0], T.n[1], T.n[2], 1.0f);
+        const V4 incident = F.hit_pos + direction;
+        const V3 refl = reflect3(xyz(incident), xyz(normal));
+        const V3 rn = normalize3(refl);
+        const V4 reflected = v4(rn.x, rn.y, rn.z, 1.0f);
+        const V4 bounce_dir = find_direction(rng, F.hit_pos, F.hit_pos + (reflected * 0.5f));
+        const V3 bn = normalize3(xyz(bounce_dir));
+        V4 new_direction = v4(bn.x, bn.y, bn.z, 1.0f);
+        if (F.scattered > 0.8) new_direction = reflected;
+        const float transmitted = (float)transmittance(F.t_s, F.avg_ext);
+        V3 ne = energy * transmitted;
+        if (!(ne.x == 0 && ne.y == 0 && ne.z == 0)) {
+          ne.x = fminf(energy.x, fmaxf(ne.x, 0.f));
+          ne.y = fminf(energy.y, fmaxf(ne.y, 0.f));
+          ne.z = fminf(energy.z, fmaxf(ne.z, 0.f));
+          Frame b;
+          b.origin = F.hit_pos + (normal * 0.0001f);
+          b.direction = new_direction;
+          b.energy = ne;
+          b.bounce = F.bounce + 1;
+          b.parity = F.parity ^ 1;
+          b.stage = 0;
+          b.ada = false;
+          st[sp] = b;   // tail call: nothing follows the bounce in the parent
+          continue;
+        }
+      }
+      sp--;
+    } else {
+      // the beam leaves through the open front: clip at four planes through the camera (:558-618)
+      const float* M = p.matrix;
+      const V4 top_left = v4(-1, -1, -1, 1), top_right = v4(1, -1, -1, 1);
+      const V4 bot_left = v4(-1, 1, -1, 1), bot_right = v4(1, 1, -1, 1);
+      const V4 converge = mul4(M, v4(0, 0, C.camera[2], 1.0f));
+      const V4 top = mul4(M, (top_left + top_right) / 2.0f);
+      const V4 right = mul4(M, (top_right + bot_right) / 2.0f);
+      const V4 bot = mul4(M, (bot_right + bot_left) / 2.0f);
+      const V4 left = mul4(M, (bot_left + top_left) / 2.0f);
+      const V3 p00 = xyz((top + converge) / 2.0f), p01 = xyz((right + converge) / 2.0f);
+      const V3 p02 = xyz((bot + converge) / 2.0f), p03 = xyz((left + converge) / 2.0f);
+      const V3 n00 = normalize3(cross3(p00 - xyz(top), xyz(mul4(M, top_left) - top)));
+      const V3 n01 = normalize3(cross3(p01 - xyz(right), xyz(mul4(M, top_right) - right)));
+      const V3 n02 = normalize3(cross3(p02 - xyz(bot), xyz(mul4(M, bot_right) - bot)));
+      const V3 n03 = normalize3(cross3(p03 - xyz(left), xyz(mul4(M, bot_left) - left)));
+      const V3 dir = normalize3(xyz(direction));
+      const V3 start = xyz(origin);
+      float t, t_min = 3.402823466e+38f;
+      if (intersect_plane(n00, p00, start, dir, t)) if (t < t_min) t_min = t;
+      if (intersect_plane(n01, p01, start, dir, t)) if (t < t_min) t_min = t;
+      if (intersect_plane(n02, p02, start, dir, t)) if (t < t_min) t_min = t;
+      if (intersect_plane(n03, p03, start, dir, t)) if (t < t_min) t_min = t;
+      if (t_min != 3.402823466e+38f) {
+        V4 end;
+        if (F.scatt) { end = origin + (F.t_s * direction); end.w = 1.0f; }
+        else { const V3 e = start + (t_min * dir); end = v4(e.x, e.y, e.z, 1.0f); }
+        push_beam<WRITE>(sink, F.parity, origin, end, omega_u, radius, energy, -1, F.ada, false);
+      }
+      sp--;
+    }
+  }
+}
+
+// CastPhotonBeams, CastPhotons.h:312-368: one photon per lane.
+template <bool WRITE>
+__global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n_photons) return;
+  const pb_control& C = p.ctl;
+  Rng rng;
+  rng.photon = (uint32_t)i; rng.draw = 0;
+  rng.k0 = (uint32_t)p.seed; rng.k1 = (uint32_t)(p.seed >> 32);
+  BeamSink sink;
+  sink.p = &p; sink.photon = (uint32_t)i; sink.order = 0; sink.n_const = 0; sink.n_scatt = 0;
+  sink.off_const = WRITE ? p.off_const[i] : 0u;
+  sink.off_scatt = WRITE ? p.off_scatt[i] : 0u;
+
+  const V4 light = v4(C.light_position[0], C.light_position[1], C.light_position[2], C.light_position[3]);
+  const V4 origin = mul4(p.matrix, light);
+  const V4 centre = v4(origin.x, (float)(origin.y + 1.5), origin.z, 1.0f);
+  V4 direction = find_direction(rng, origin, centre);
+  direction = normalize4(direction);
+  float r = (float)rng.uniform_beam();
+  float r_small = (float)rng.uniform_small();
+  if (C.fixed_radius) { r = C.radius; r_small = r; }
+  const V3 w_u = normalize3(v3(direction.x + r_small, direction.y, direction.z));
+  const V4 omega_u = v4(w_u.x, w_u.y, w_u.z, 1.0f);
+  const float t = (float)(2 * PB_PI_REF * rng.uniform_radius());
+  const double u1 = rng.uniform_radius();
+  const double u2 = rng.uniform_radius();
+  const float u = (float)(u1 + u2);
+  const float w_width = (u > 1) ? 2 - u : u;
+  const float x_offset = w_width * cosf(t);
+  const float y_offset = (float)(rng.uniform_offset() * 0.1);
+  const float z_offset = w_width * sinf(t);
+  Frame f;
+  f.origin = origin + v4(x_offset, y_offset, z_offset, 0);
+  f.direction = direction;
+  f.energy = v3(C.light_power[0], C.light_power[1], C.light_power[2]);
+  f.bounce = 0; f.parity = 0; f.stage = 0; f.ada = C.adaptive != 0;
+  cast_beam<WRITE>(p, rng, sink, f, omega_u, r);
+  if (!WRITE) { p.cnt_const[i] = sink.n_const; p.cnt_scatt[i] = sink.n_scatt; }
+}
+
+// ---------------------------------------------------------------- segments --
+struct BoundParams {
+  const pb_beam* beams;       // beams_const list then beams_scattered list
+  int n_const, n_scatt;
+  float extinction_c;
+  uint32_t* seg_count;        // counting pass
+  const uint32_t* seg_offset; // writing pass
+  pb_segment* segs;
+};
+
+// BoundPhotonBeams (CastPhotons.h:144-288), homogeneous medium: the whole beam
+// becomes one segment, plus a second, ~1e-7-long one whenever the float length of
+// prior + dir*len - start falls short of len (:196-202).
+template <bool WRITE>
+__global__ __launch_bounds__(256) void bound_kernel(const BoundParams p) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = p.n_const + p.n_scatt;
+  if (g >= n) return;
+  const pb_beam b = p.beams[g];
+  const int i = (g < p.n_const) ? g : g - p.n_const;   // index in its own list: PhotonSeg.id (:227)
+  const V4 start = v4(b.start[0], b.start[1], b.start[2], b.start[3]);
+  const V4 end = v4(b.end[0], b.end[1], b.end[2], b.end[3]);
+  const V3 diff = xyz(end) - xyz(start);
+  const V3 dir = normalize3(diff);
+  const float len = length3(diff);
+  float j = 0;
+  const V3 x_dir = normalize3(v3(1, 0, 0)), y_dir = normalize3(v3(0, 1, 0)), z_dir = normalize3(v3(0, 0, 1));
+  const float theta_x = fminf(acosf(dot3(dir, x_dir)), acosf(dot3(dir, -x_dir)));
+  const float theta_y = fminf(acosf(dot3(dir, y_dir)), acosf(dot3(dir, -y_dir)));
+  const float theta_z = fminf(acosf(dot3(dir, z_dir)), acosf(dot3(dir, -z_dir)));
+  const float step = len;
+  const bool ada = (b.flags & 1u) != 0;
+  // BeamRadiance.h:449-455 always looks the energy up in beams_const[id]
+  float en[3] = {0.f, 0.f, 0.f};
+  if (WRITE && i < p.n_const) { en[0] = p.beams[i].energy[0]; en[1] = p.beams[i].energy[1]; en[2] = p.beams[i].energy[2]; }
+  V3 prior = v3(start.x, start.y, start.z);
+  uint32_t count = 0;
+  const uint32_t base = WRITE ? p.seg_offset[g] : 0u;
+  while (j < len && len > 1e-6) {
+    const V3 next = prior + (dir * step);
+    const V3 s_start = prior;
+    V3 s_end;
+    if (len <= length3(next - xyz(start))) { j = fabsf(len); s_end = xyz(end); }
+    else { j = length3(next - xyz(start)); s_end = next; }
+    prior = s_end;
+    float radius;
+    if (ada) {
+      const V3 ou = v3(b.omega_u[0], b.omega_u[1], b.omega_u[2]);
+      const V3 omega_u = normalize3(ou);
+      const float cos_theta = dot3(dir, omega_u);
+      const float hyp_length = j / cos_theta;
+      const V4 end_u = start + (v4(b.omega_u[0], b.omega_u[1], b.omega_u[2], b.omega_u[3]) * hyp_length);
+      radius = length3(s_end - xyz(end_u));
+    } else radius = b.radius;
+    if (WRITE) {
+      float mnx = fminf(s_start.x, s_end.x), mny = fminf(s_start.y, s_end.y), mnz = fmaxf(s_start.z, s_end.z);
+      float mxx = fmaxf(s_start.x, s_end.x), mxy = fmaxf(s_start.y, s_end.y), mxz = fminf(s_start.z, s_end.z);
+      if (len > 0.001) {
+        float th; int axis;
+        if (theta_x < theta_y && theta_x < theta_z) { th = theta_x; axis = 0; }
+        else if (theta_y < theta_z) { th = theta_y; axis = 1; }
+        else { th = theta_z; axis = 2; }
+        const float hypotenuse = radius / sinf(th);
+        const float adj = radius / cosf(th);
+        const float height = adj * sinf(th);
+        const float px = (axis == 0) ? height : hypotenuse;
+        const float py = (axis == 1) ? height : hypotenuse;
+        const float pz = (axis == 2) ? height : hypotenuse;
+        mnx = mnx - px; mny = mny - py; mnz = mnz + pz;
+        mxx = mxx + px; mxy = mxy + py; mxz = mxz - pz;
+      }
+      pb_segment s;
+      s.start[0] = s_start.x; s.start[1] = s_start.y; s.start[2] = s_start.z;
+      s.end[0] = s_end.x; s.end[1] = s_end.y; s.end[2] = s_end.z;
+      s.orig_start[0] = start.x; s.orig_start[1] = start.y; s.orig_start[2] = start.z;
+      s.radius = radius;
+      // PhotonSeg.min/max store z flipped; the gate uses min_b = (min.x, min.y, max.z)
+      s.cull_lo[0] = mnx; s.cull_lo[1] = mny; s.cull_lo[2] = mxz;
+      s.cull_hi[0] = mxx; s.cull_hi[1] = mxy; s.cull_hi[2] = mnz;
+      s.energy[0] = en[0]; s.energy[1] = en[1]; s.energy[2] = en[2];
+      s.s_ext = 0.f; s.e_ext = 0.f; s.c_ext = p.extinction_c;
+      s.seg_id = 1; s.id = i;
+      s.flags = ada ? 1u : 0u;
+      s.reserved[0] = s.reserved[1] = s.reserved[2] = 0u;
+      p.segs[base + count] = s;
+    }
+    count++;
+  }
+  if (!WRITE) p.seg_count[g] = count;
+}
+
+// Root box of CastPhotonBeams (CastPhotons.h:507-512, :384-387): bounds of all beam end points.
+__global__ __launch_bounds__(1024) void root_box_kernel(const pb_beam* __restrict__ beams, int n, float* __restrict__ out6) {
+  __shared__ float red[6][1024 / 64];
+  float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+  float hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const pb_beam b = beams[i];
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = fminf(lo[k], fminf(b.start[k], b.end[k]));
+      hi[k] = fmaxf(hi[k], fmaxf(b.start[k], b.end[k]));
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 3; ++k) {
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_down(lo[k], off, 64));
+      hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off, 64));
+    }
+    if (lane == 0) { red[k][wave] = lo[k]; red[3 + k][wave] = hi[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    float v = red[k][0];
+    for (int w = 1; w < 1024 / 64; ++w) v = (k < 3) ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+    out6[k] = v;
+  }
+}
+
+struct TmpBuffers {
+  uint32_t* a = nullptr;
+  ~TmpBuffers() { if (a) (void)hipFree(a); }
+};
+
+}  // namespace
+
+int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
+  if (ctx->ctl.heterogeneous) { pb_set_error("pb_emit_beams: the heterogeneous medium is not implemented yet"); return PB_ERR_STATE; }
+  hipStream_t s = ctx->stream;
+  PB_HIP(hipEventRecord(ctx->ev[6], s));
+  // scratch: cnt_const[n] cnt_scatt[n] off_const[n] off_scatt[n] totals[4] dropped[1] root[6] + scan tmp
+  const size_t n = (size_t)n_photons;
+  const size_t scan_words = pb_scan_tmp_words(n_photons > 0 ? n_photons : 1);
+  TmpBuffers tmp;
+  const size_t head = 4 * n + 16;
+  PB_HIP(hipMalloc(&tmp.a, sizeof(uint32_t) * (head + scan_words)));
+  PB_HIP(hipMemsetAsync(tmp.a, 0, sizeof(uint32_t) * (head + scan_words), s));
+  uint32_t* cnt_const = tmp.a; uint32_t* cnt_scatt = tmp.a + n;
+  uint32_t* off_const = tmp.a + 2 * n; uint32_t* off_scatt = tmp.a + 3 * n;
+  uint32_t* totals = tmp.a + 4 * n;            // [0] n_const [1] n_scatt [2] n_seg [3] dropped
+  float* d_root = (float*)(tmp.a + 4 * n + 8); // 6 floats
+  uint32_t* scan_tmp = tmp.a + head;
+
+  EmitParams ep;
+  std::memset(&ep, 0, sizeof(ep));
+  ep.tris = ctx->d_tris; ep.n_tri = ctx->n_tri;
+  for (int k = 0; k < 16; ++k) ep.matrix[k] = ctx->matrix[k];
+  ep.ctl = ctx->ctl; ep.seed = seed; ep.n_photons = n_photons;
+  ep.cnt_const = cnt_const; ep.cnt_scatt = cnt_scatt; ep.off_const = off_const; ep.off_scatt = off_scatt;
+  ep.dropped = totals + 3;
+  const int blocks = (n_photons + EMIT_THREADS - 1) / EMIT_THREADS;
+  if (n_photons > 0) hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+  PB_HIP(hipGetLastError());
+  int rc = pb_exclusive_scan_u32(cnt_const, off_const, n_photons, totals + 0, scan_tmp, s);
+  if (rc != PB_OK) return rc;
+  rc = pb_exclusive_scan_u32(cnt_scatt, off_scatt, n_photons, totals + 1, scan_tmp, s);
+  if (rc != PB_OK) return rc;
+  uint32_t h_tot[4] = {0, 0, 0, 0};
+  PB_HIP(hipMemcpyAsync(h_tot, totals, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, s));
+  PB_HIP(hipStreamSynchronize(s));
+  const int nc = (int)h_tot[0], ns = (int)h_tot[1], nb = nc + ns;
+
+  if (ctx->d_beams) { PB_HIP(hipFree(ctx->d_beams)); ctx->d_beams = nullptr; }
+  ctx->n_beams_const = 0; ctx->n_beams_scatt = 0;
+  PB_HIP(hipMalloc(&ctx->d_beams, sizeof(pb_beam) * (size_t)(nb > 0 ? nb : 1)));
+  ep.beams_const = ctx->d_beams; ep.beams_scatt = ctx->d_beams + nc;
+  PB_HIP(hipMemsetAsync(totals + 3, 0, sizeof(uint32_t), s));   // the counting pass reported the same drops
+  if (n_photons > 0) hipLaunchKernelGGL(emit_kernel<true>, dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+  PB_HIP(hipGetLastError());
+  ctx->n_beams_const = nc; ctx->n_beams_scatt = ns;
+
+  // segments
+  uint32_t* seg_buf = nullptr;
+  TmpBuffers tmp2;
+  const size_t scan_words2 = pb_scan_tmp_words(nb > 0 ? nb : 1);
+  PB_HIP(hipMalloc(&tmp2.a, sizeof(uint32_t) * (2 * (size_t)(nb > 0 ? nb : 1) + scan_words2)));
+  seg_buf = tmp2.a;
+  uint32_t* seg_count = seg_buf; uint32_t* seg_offset = seg_buf + (nb > 0 ? nb : 1);
+  uint32_t* scan_tmp2 = seg_buf + 2 * (size_t)(nb > 0 ? nb : 1);
+  BoundParams bp;
+  std::memset(&bp, 0, sizeof(bp));
+  bp.beams = ctx->d_beams; bp.n_const = nc; bp.n_scatt = ns;
+  bp.extinction_c = ctx->ctl.absorption_c + ctx->ctl.scattering_c;
+  bp.seg_count = seg_count; bp.seg_offset = seg_offset;
+  if (nb > 0) hipLaunchKernelGGL(bound_kernel<false>, dim3((nb + 255) / 256), dim3(256), 0, s, bp);
+  PB_HIP(hipGetLastError());
+  rc = pb_exclusive_scan_u32(seg_count, seg_offset, nb, totals + 2, scan_tmp2, s);
+  if (rc != PB_OK) return rc;
+  if (nb > 0) hipLaunchKernelGGL(root_box_kernel, dim3(1), dim3(1024), 0, s, ctx->d_beams, nb, d_root);
+  PB_HIP(hipGetLastError());
+  float h_root[6] = {0, 0, 0, 0, 0, 0};
+  PB_HIP(hipMemcpyAsync(h_tot, totals, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+  PB_HIP(hipMemcpyAsync(h_root, d_root, sizeof(float) * 6, hipMemcpyDeviceToHost, s));
+  PB_HIP(hipStreamSynchronize(s));
+  const int nseg = (int)h_tot[2];
+  rc = pb_ensure_segment_capacity(ctx, nseg);
+  if (rc != PB_OK) return rc;
+  bp.segs = ctx->d_segs;
+  if (nb > 0) hipLaunchKernelGGL(bound_kernel<true>, dim3((nb + 255) / 256), dim3(256), 0, s, bp);
+  PB_HIP(hipGetLastError());
+  ctx->n_seg = nseg;
+  for (int k = 0; k < 3; ++k) { ctx->root_lo[k] = h_root[k]; ctx->root_hi[k] = h_root[3 + k]; }
+  rc = pb_prepare_frames(ctx, pb_default_mode(ctx), s);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipEventRecord(ctx->ev[7], s));
+  ctx->ev_valid[3] = true;
+  PB_HIP(hipStreamSynchronize(s));
+  ctx->have_segments = true;
+  if (h_tot[3] != 0) {
+    pb_set_error("pb_emit_beams: " + std::to_string(h_tot[3]) + " nested scattering events exceeded the per-photon stack and were dropped");
+    return PB_ERR_CAPACITY;
+  }
+  return PB_OK;
+}

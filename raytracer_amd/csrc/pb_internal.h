@@ -81,6 +81,44 @@ enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, 
 
 void pb_set_error(const std::string& msg);
 
+// One GPU's state (opaque to callers of the C ABI).
+struct pb_ctx {
+  pb_control ctl;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};   // pairs: 0,1 render; 2,3 prepare; 4,5 build; 6,7 emit
+  bool ev_valid[4] = {false, false, false, false};
+  // scene
+  float* d_tri_xyz = nullptr;
+  float* d_matrix = nullptr;
+  TriPrep* d_tris = nullptr;
+  int n_tri = 0;
+  float matrix[16];
+  // beams of the last pb_emit_beams: beams_const list, then beams_scattered list
+  pb_beam* d_beams = nullptr;
+  int n_beams_const = 0, n_beams_scatt = 0;
+  // segments
+  pb_segment* d_segs = nullptr;
+  SegFrame* d_frames = nullptr;
+  float4* d_capA = nullptr;
+  float4* d_capB = nullptr;
+  int n_seg = 0, cap_seg = 0, frame_mode = 0;
+  bool have_segments = false;
+  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+  // output staging for the host-pointer render
+  float* d_out = nullptr;
+  size_t out_floats = 0;
+  // counters
+  unsigned long long* d_counters = nullptr;
+  bool count_on = false;
+  pb_stats stats;
+};
+
+int pb_ensure_segment_capacity(pb_ctx* ctx, int n);
+int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s);
+int pb_default_mode(const pb_ctx* ctx);
+int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed);
+
 #define PB_HIP(call)                                                                         \
   do {                                                                                       \
     hipError_t e_ = (call);                                                                  \

@@ -10,6 +10,7 @@
 // BeamRadiance.h:426-430) is discontinuous in its inputs and is evaluated with
 // the reference's exact operation order.
 #include "pb_internal.h"
+#include "pb_geom.h"
 
 namespace {
 
@@ -19,44 +20,6 @@ struct Ray {
   float maxd;  // |limit.position - start|          BeamRadiance.h:426
   bool active;
 };
-
-// ClosestIntersection, Intersections.h:458-497, on prepared triangles.
-PB_DI bool closest_intersection(const TriPrep* __restrict__ tris, int n_tri, V4 start, V4 dir, V4& position,
-                                float& distance, int& index) {
-  bool found = false;
-  float best = 3.402823466e+38f;   // Intersections.h:57
-  int best_i = -1;
-  const float ndx = -dir.x, ndy = -dir.y, ndz = -dir.z;
-  for (int i = 0; i < n_tri; ++i) {
-    const TriPrep& T = tris[i];
-    const float bx = start.x - T.v0[0], by = start.y - T.v0[1], bz = start.z - T.v0[2];
-    const float e1x = T.e1[0], e1y = T.e1[1], e1z = T.e1[2];
-    const float e2x = T.e2[0], e2y = T.e2[1], e2z = T.e2[2];
-    const float P = ndy * e2z - e2y * ndz;
-    const float Q = ndy * e1z - e1y * ndz;
-    const float det = ndx * T.c0 - e1x * P + e2x * Q;
-    const float ood = 1.0f / det;
-    const float i00 = T.c0 * ood;
-    const float i10 = -T.c1 * ood;
-    const float i20 = T.c2 * ood;
-    const float i01 = -P * ood;
-    const float i11 = (ndx * e2z - e2x * ndz) * ood;
-    const float i21 = -(ndx * e2y - e2x * ndy) * ood;
-    const float i02 = Q * ood;
-    const float i12 = -(ndx * e1z - e1x * ndz) * ood;
-    const float i22 = (ndx * e1y - e1x * ndy) * ood;
-    const float xx = i00 * bx + i10 * by + i20 * bz;
-    const float xy = i01 * bx + i11 * by + i21 * bz;
-    const float xz = i02 * bx + i12 * by + i22 * bz;
-    if (xx >= 0 && xy >= 0 && xz >= 0 && (xy + xz) < 1) {
-      if (xx < best) { found = true; best = xx; best_i = i; }
-    }
-  }
-  distance = best;
-  index = best_i;
-  if (found) position = start + dir * best;
-  return found;
-}
 
 // HitBoundingBox (Intersections.h:81-143) for a ray from (0,0,0) followed by the
 // distance test of BeamRadiance.h:429-430.  lo/hi are min_b/max_b, cand/qflags
@@ -226,6 +189,14 @@ __global__ __launch_bounds__(64) void render_tiles_721_kernel(const RenderParams
       pl[2] = normalize3(v3(0.0f, p.focal, -yt));
       pl[3] = normalize3(v3(0.0f, -p.focal, yb));
 
+      if (COUNT) {
+        // the pairs on which the reference calls HitCylinder: both gates pass, cylinder or not
+        if (box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd))
+          for (int sidx = 0; sidx < p.n_seg; ++sidx) {
+            const SegFrame& f = p.frames[sidx];
+            c_gated += box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd) ? 1 : 0;
+          }
+      }
       for (int base = 0; base < p.n_seg; base += 64) {
         const int s = base + lane;
         bool touch = false;
@@ -238,7 +209,7 @@ __global__ __launch_bounds__(64) void render_tiles_721_kernel(const RenderParams
           const SegFrame& f = p.frames[sidx];
           bool gated = false;
           const int res = eval_pair_721(f, r, p.root, p.extinction_c, acc, gated);
-          if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; c_gated += gated ? 1 : 0; }
+          if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
         }
       }
     }

@@ -315,8 +315,9 @@ def max_threads():
 
 
 def render_segments(control, tri_xyz9, m16, segs, root_lo, root_hi, x0, y0, w, h, mode=MODE_721,
-                    grid_sigma=None, side=0, threads=0):
-    """The flat estimate the GPU implements, on the CPU: (h,w,3) float64 and counters."""
+                    grid_sigma=None, side=0, threads=0, step_x=1, step_y=1):
+    """The flat estimate the GPU implements, on the CPU: (h,w,3) float64 and counters.
+    With steps > 1 the pixels are (x0 + i*step_x, y0 + j*step_y)."""
     rgb = np.zeros((h, w, 3), np.float64)
     cnt = Counters()
     segs = np.ascontiguousarray(segs)
@@ -324,11 +325,12 @@ def render_segments(control, tri_xyz9, m16, segs, root_lo, root_hi, x0, y0, w, h
     t = _f32(tri_xyz9)
     g = _f32(grid_sigma) if grid_sigma is not None else None
     threads = threads or max_threads()
-    r = lib().orc_render_segments(C.byref(control), _fp(t), C.c_int(t.size // 9), _fp(_f32(m16, 16)),
+    r = lib().orc_render_segments_strided(C.byref(control), _fp(t), C.c_int(t.size // 9), _fp(_f32(m16, 16)),
                                   _fp(g) if g is not None else None, C.c_int(side),
                                   segs.ctypes.data_as(C.c_void_p), C.c_int(len(segs)),
                                   _fp(_f32(root_lo, 3)), _fp(_f32(root_hi, 3)),
-                                  C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h), C.c_int(mode),
+                                  C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h), C.c_int(step_x), C.c_int(step_y),
+                                  C.c_int(mode),
                                   rgb.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.c_int(threads))
     assert r == 0, r
     return rgb, cnt.as_dict()

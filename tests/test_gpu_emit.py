@@ -1,0 +1,110 @@
+"""GPU photon pass (pb_emit_beams = CastPhotonBeams + BoundPhotonBeams) against the CPU oracle driven by
+the same counter-based random numbers.  Indexing (counts, photon, order, list, beam index of every
+segment) is exact; coordinates agree to float tolerance (device and host libm differ in the last bits
+of sin/cos/log/acos), stated per assertion."""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pb():
+    import raytracer_amd as pb
+    if pb.device_count() < 1:
+        pytest.fail("no GPU visible: the HIP path cannot run (there is no CPU fallback)")
+    return pb
+
+
+def oracle_pass(n_photons, bounces, seed=42):
+    c = orc.control_defaults(photon_number=n_photons, bounces=bounces, seed=seed)
+    o = orc.Oracle(c)
+    o.cast_photon_beams(rng_kind=1)
+    o.bound_photon_beams()
+    return o
+
+
+@pytest.mark.parametrize("n_photons,bounces", [(1000, 0), (3000, 3)])
+def test_emission_matches_oracle(pb, n_photons, bounces):
+    o = oracle_pass(n_photons, bounces)
+    ob = o.beams()
+    oseg = o.export_segments(tree=False)
+    with pb.Context(pb.control_defaults(photon_number=n_photons, bounces=bounces)) as ctx:
+        ctx.set_scene()
+        nb, ns = ctx.cast_photon_beams()
+        gb = ctx.download_beams()
+        gseg = ctx.download_segments()
+        glo, ghi = ctx.root_box()
+        assert ctx.beam_counts() == o.beam_counts()
+    assert nb == len(ob)
+    # exact: which photon pushed which beam, in which order, into which list, hitting which triangle
+    for f in ("photon", "order", "flags", "index_hit"):
+        assert np.array_equal(gb[f], ob[f]), f
+    for f in ("start", "end"):
+        np.testing.assert_allclose(gb[f], ob[f], rtol=0, atol=2e-5, err_msg=f)
+    np.testing.assert_allclose(gb["radius"], ob["radius"], rtol=1e-6)
+    np.testing.assert_allclose(gb["energy"], ob["energy"], rtol=1e-5)
+    # most beams are bit-identical; the rest differ in the last bits of a libm call
+    same = (gb["start"] == ob["start"]).all(1) & (gb["end"] == ob["end"]).all(1)
+    assert same.mean() > 0.5, same.mean()
+    # Segments.  Every beam gives one segment that starts at the beam start; about one beam in ten also
+    # gives a ~1e-7-long tail (CastPhotons.h:196-202) whose existence hangs on the last bit of the beam's
+    # end point, so tails are compared only for beams whose end points are bit-identical on both sides.
+    gmain = (gseg["start"] == gseg["orig_start"]).all(1); omain = (oseg["start"] == oseg["orig_start"]).all(1)
+    assert gmain.sum() == nb and omain.sum() == nb and ns == len(gseg)
+    gm, om = gseg[gmain], oseg[omain]
+    for f in ("id", "seg_id", "flags"):
+        assert np.array_equal(gm[f], om[f]), f
+    for f in ("start", "end", "orig_start"):
+        np.testing.assert_allclose(gm[f], om[f], rtol=0, atol=2e-5, err_msg=f)
+    for f in ("cull_lo", "cull_hi"):
+        np.testing.assert_allclose(gm[f], om[f], rtol=0, atol=5e-4, err_msg=f)   # r/sin(theta) padding
+    np.testing.assert_allclose(gm["energy"], om["energy"], rtol=1e-5)
+    g_tail = np.diff(np.append(np.flatnonzero(gmain), len(gseg))) == 2
+    o_tail = np.diff(np.append(np.flatnonzero(omain), len(oseg))) == 2
+    assert np.array_equal(g_tail[same], o_tail[same])
+    assert 0.02 < g_tail.mean() < 0.3
+    gt = gseg[~gmain]
+    assert (np.linalg.norm(gt["end"] - gt["start"], axis=1) < 1e-5).all()
+    olo, ohi = o.root_box()
+    np.testing.assert_allclose(glo, olo, atol=2e-5); np.testing.assert_allclose(ghi, ohi, atol=2e-5)
+
+
+def test_emission_is_launch_independent_and_seeded(pb):
+    with pb.Context(pb.control_defaults(photon_number=500, bounces=2)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams(500, seed=7)
+        a = ctx.download_segments().copy()
+        ctx.cast_photon_beams(1500, seed=7)
+        b = ctx.download_beams().copy()
+        ctx.cast_photon_beams(500, seed=7)
+        c = ctx.download_segments()
+        ctx.cast_photon_beams(500, seed=8)
+        d = ctx.download_segments()
+    assert a.tobytes() == c.tobytes()
+    assert len(d) != len(a) or d.tobytes() != a.tobytes()
+    # photons are independent streams: the first 500 photons of a 1500-photon pass are the 500-photon pass
+    assert (np.diff(b["photon"][(b["flags"] & 8) == 0].astype(np.int64)) >= 0).all()
+
+
+def test_render_of_gpu_emitted_set_matches_oracle(pb):
+    """Own-box gate rule on a 2000-photon, 2-bounce set emitted on the GPU: GPU frame vs oracle on a
+    lattice of pixels (every 4th in x and y)."""
+    ctl = pb.control_defaults(photon_number=2000, bounces=2)
+    with pb.Context(ctl) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        img = ctx.draw().astype(np.float64)
+    tri, _ = orc.load_test_model()
+    octl = orc.control_defaults(photon_number=2000, bounces=2)
+    ref, cnt = orc.render_segments(octl, orc.tri_xyz(tri), orc.transformation_matrix(), segs, lo, hi,
+                                   1, 2, 128, 128, step_x=4, step_y=4)
+    got = img[2::4, 1::4][:128, :128]
+    err = np.abs(got - ref)
+    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), err.max()
+    assert np.sqrt((err ** 2).mean()) <= 1e-4
+    assert ref.max() > 1.0 and cnt["valid_hits"] > 10000
