@@ -73,6 +73,26 @@ int pb_default_mode(const pb_ctx* ctx) { return default_mode(ctx); }
 
 namespace {
 
+int ensure_workspace(pb_ctx* ctx, int groups, int chunks) {
+  if (groups > ctx->ws_groups) {
+    if (ctx->d_rays) PB_HIP(hipFree(ctx->d_rays));
+    if (ctx->d_group_last) PB_HIP(hipFree(ctx->d_group_last));
+    ctx->d_rays = nullptr; ctx->d_group_last = nullptr; ctx->ws_groups = 0;
+    PB_HIP(hipMalloc(&ctx->d_rays, sizeof(float) * 8 * 64 * (size_t)groups));
+    PB_HIP(hipMalloc(&ctx->d_group_last, sizeof(int) * (size_t)groups));
+    ctx->ws_groups = groups;
+  }
+  if (chunks > ctx->ws_chunks) {
+    if (ctx->d_chunks) PB_HIP(hipFree(ctx->d_chunks));
+    if (ctx->d_partials) PB_HIP(hipFree(ctx->d_partials));
+    ctx->d_chunks = nullptr; ctx->d_partials = nullptr; ctx->ws_chunks = 0;
+    PB_HIP(hipMalloc(&ctx->d_chunks, sizeof(uint32_t) * PB_CHUNK_WORDS * (size_t)chunks));
+    PB_HIP(hipMalloc(&ctx->d_partials, sizeof(double) * 3 * 64 * (size_t)chunks));
+    ctx->ws_chunks = chunks;
+  }
+  return PB_OK;
+}
+
 int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_stride, int mode, int use_lbvh,
                   float* d_out, hipStream_t s) {
   if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
@@ -96,8 +116,43 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.out = d_out;
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
-  PB_HIP(hipEventRecord(ctx->ev[0], s));
-  int rc = pb_launch_render(p, mode, ctx->count_on, s);
+
+  // The chunk pool must hold every candidate chunk of this frame.  Its size depends on the segment set
+  // and the frame geometry only, so it is measured (one host synchronisation) the first time a given
+  // combination is rendered and trusted afterwards.
+  const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
+  const unsigned long long key[6] = {ctx->segs_version,
+                                     ((unsigned long long)(uint32_t)x0 << 32) | (uint32_t)y0,
+                                     ((unsigned long long)(uint32_t)out_w << 32) | (uint32_t)out_h,
+                                     (unsigned long long)strip_stride,
+                                     (unsigned long long)(use_lbvh ? 1 : 0),
+                                     (unsigned long long)mode};
+  bool verified = std::memcmp(key, ctx->ws_key, sizeof(key)) == 0;
+  int want_chunks = ctx->ws_chunks;
+  if (!verified && want_chunks < groups * 2 + 1024) want_chunks = groups * 2 + 1024;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    int rc = ensure_workspace(ctx, groups, want_chunks);
+    if (rc != PB_OK) return rc;
+    p.rays = ctx->d_rays; p.group_last = ctx->d_group_last; p.chunks = ctx->d_chunks;
+    p.partials = ctx->d_partials; p.ctrl = ctx->d_ctrl; p.chunk_capacity = ctx->ws_chunks;
+    PB_HIP(hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * 4, s));
+    PB_HIP(hipEventRecord(ctx->ev[0], s));
+    rc = pb_launch_cull(p, mode, ctx->count_on, s);
+    if (rc != PB_OK) return rc;
+    if (verified) break;
+    PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+    PB_HIP(hipStreamSynchronize(s));
+    const uint32_t needed = ctx->h_ctrl[0];
+    if (needed <= (uint32_t)ctx->ws_chunks) {
+      std::memcpy(ctx->ws_key, key, sizeof(key));
+      verified = true;
+      break;
+    }
+    want_chunks = (int)(needed + needed / 4 + 64);
+    if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
+  }
+  if (!verified) { pb_set_error("pb_render: candidate chunk pool could not be sized"); return PB_ERR_CAPACITY; }
+  int rc = pb_launch_eval_reduce(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
   PB_HIP(hipEventRecord(ctx->ev[1], s));
   ctx->ev_valid[0] = true;
@@ -150,6 +205,8 @@ int pb_create(const pb_control* control, int device, pb_ctx** out) {
   PB_HIP(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * PB_CNT_N));
   PB_HIP(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N));
   PB_HIP(hipMalloc(&ctx->d_matrix, sizeof(float) * 16));
+  PB_HIP(hipMalloc(&ctx->d_ctrl, sizeof(uint32_t) * 4));
+  PB_HIP(hipHostMalloc(&ctx->h_ctrl, sizeof(uint32_t) * 4));
   *out = ctx;
   return PB_OK;
 }
@@ -159,8 +216,10 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
-                  ctx->d_out, ctx->d_counters, ctx->d_beams};
+                  ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_rays, ctx->d_group_last,
+                  ctx->d_chunks, ctx->d_partials, ctx->d_ctrl};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -191,6 +250,7 @@ int pb_set_scene(pb_ctx* ctx, const float* tri_xyz, int n_tri, const float matri
   if (rc != PB_OK) return rc;
   PB_HIP(hipStreamSynchronize(ctx->stream));
   ctx->n_tri = n_tri;
+  ctx->segs_version++;
   std::memcpy(ctx->matrix, matrix, sizeof(float) * 16);
   return PB_OK;
 }
@@ -216,6 +276,7 @@ static int upload_common(pb_ctx* ctx, const pb_segment* src, bool src_on_device,
   rc = pb_prepare_frames(ctx, default_mode(ctx), s);
   if (rc != PB_OK) return rc;
   ctx->have_segments = true;
+  ctx->segs_version++;
   return PB_OK;
 }
 

@@ -517,6 +517,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
   ctx->ev_valid[3] = true;
   PB_HIP(hipStreamSynchronize(s));
   ctx->have_segments = true;
+  ctx->segs_version++;
   if (h_tot[3] != 0) {
     pb_set_error("pb_emit_beams: " + std::to_string(h_tot[3]) + " nested scattering events exceeded the per-photon stack and were dropped");
     return PB_ERR_CAPACITY;

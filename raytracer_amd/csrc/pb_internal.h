@@ -72,10 +72,21 @@ struct RenderParams {
   int x0, y0, out_w, out_h, strip_stride, tiles_x, tiles_y;
   float* out;              // out_h * out_w * 3
   unsigned long long* counters;  // 8 words or nullptr
+  // workspace of one frame (see pb_render.hip)
+  float* rays;              // [groups][8][64]: l.xyz, dn.xyz, maxd, 0
+  int* group_last;          // [groups]: last chunk of the group's list, -1 if none
+  uint32_t* chunks;         // [chunk_capacity][PB_CHUNK_WORDS]: group, count, prev, 0, indices
+  double* partials;         // [chunk_capacity][3][64]
+  uint32_t* ctrl;           // [0] chunks produced, [1] chunks taken by eval waves
+  int chunk_capacity;
   // LBVH (null: scan all segments)
   const void* lbvh_nodes;
   const uint32_t* lbvh_perm;
 };
+
+constexpr int PB_CHUNK = 124;          // candidates per chunk
+constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 512 B
+constexpr int PB_EVAL_WAVES = 256 * 32; // one resident wave slot per SIMD lane group of the chip
 
 enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_N };
 
@@ -108,6 +119,16 @@ struct pb_ctx {
   // output staging for the host-pointer render
   float* d_out = nullptr;
   size_t out_floats = 0;
+  // frame workspace
+  float* d_rays = nullptr;
+  int* d_group_last = nullptr;
+  uint32_t* d_chunks = nullptr;
+  double* d_partials = nullptr;
+  uint32_t* d_ctrl = nullptr;
+  uint32_t* h_ctrl = nullptr;          // pinned
+  int ws_groups = 0, ws_chunks = 0;
+  unsigned long long segs_version = 0; // bumped whenever the segment set or scene changes
+  unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // frame geometry the chunk capacity was verified for
   // counters
   unsigned long long* d_counters = nullptr;
   bool count_on = false;
@@ -132,6 +153,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed);
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matrix16, TriPrep* d_out, hipStream_t s);
 int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float scattering_c, SegFrame* d_frames,
                                float4* d_capA, float4* d_capB, hipStream_t s);
-int pb_launch_render(const RenderParams& p, int mode, bool count, hipStream_t s);
+int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
+int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);
 
 #endif

@@ -68,8 +68,7 @@ PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
 // the two gates, Integral_721 (BeamRadiance.h:86-110) and the accumulation of
 // BeamRadianceStandard (BeamRadiance.h:441-455).  Returns 0 = no cylinder hit,
 // 1 = discriminant >= 0 but no contribution, 2 = contributed.
-PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, const GateBox& root, float extinction, double acc[3],
-                        bool& gated) {
+PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, double acc[3]) {
   const V3 l = r.l;
   const float dpx = f.Rinv[0] * l.x + f.Rinv[3] * l.y + f.Rinv[6] * l.z;
   const float dpz = f.Rinv[2] * l.x + f.Rinv[5] * l.y + f.Rinv[8] * l.z;
@@ -108,10 +107,8 @@ PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, const GateBox& root, fl
     else { float th2 = t0 + (t1 - t0) * (y0) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
   } else return 1;
   if (!((t0 > 0) && (t1 > 0) && (t1 > t0))) return 1;
-  // the two gates of the traversal: tree root, then the segment's own gate box
-  if (!box_gate(root.lo, root.hi, root.cand, root.qflags, r.dn, r.maxd)) return 1;
+  // the segment's gate box; the root gate was applied to the ray (maxd < 0 if it failed)
   if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
-  gated = true;
   const float fx = ox + dpx * thf, fy = oy + dpy * thf, fz = oz + dpz * thf;
   // second_hit is unset in the reference when no branch assigned it; that never
   // coincides with valid == true, (0,0,0) stands in as in the CPU restatement
@@ -157,74 +154,122 @@ PB_DI bool capsule_touches_pyramid(const float4 A, const float4 B, const V3 pl[4
   return ok;
 }
 
+// ---------------------------------------------------------------------------
+// Frame = three launches.
+//  cull_kernel    one wave per ray group (an 8x8 tile, one sub-sample): sets up the 64 rays, stores them,
+//                 finds the segments whose capsule can touch the tile pyramid (one segment or LBVH node per
+//                 lane) and appends their indices to chunks of PB_CHUNK candidates taken from a pool.
+//  eval_kernel    a fixed grid of waves pulls chunks from a work counter; a wave evaluates the 64 rays of
+//                 the chunk's group against the chunk's candidates and stores 64 x 3 partial sums.  A tile
+//                 over the light source has two orders of magnitude more candidates than the median tile;
+//                 cutting it into chunks is what keeps one wave from serialising it.
+//  reduce_kernel  one wave per tile adds the partial sums of the tile's chunks in list order (the same
+//                 order every run) and writes current / SSAA.
+// ---------------------------------------------------------------------------
+
+PB_DI uint32_t lanes_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+struct ChunkWriter {
+  uint32_t* buf;      // LDS, PB_CHUNK + 64 entries
+  uint32_t count;     // wave-uniform
+  int prev;           // last chunk written for this group, -1 if none
+  int group;
+};
+
+PB_DI void flush_chunk(const RenderParams& p, ChunkWriter& w, uint32_t n, int lane) {
+  uint32_t c = 0;
+  if (lane == 0) c = atomicAdd(&p.ctrl[0], 1u);
+  c = __builtin_amdgcn_readfirstlane(c);
+  if (c < (uint32_t)p.chunk_capacity) {
+    uint32_t* dst = p.chunks + (size_t)c * PB_CHUNK_WORDS;
+    if (lane == 0) { dst[0] = (uint32_t)w.group; dst[1] = n; dst[2] = (uint32_t)w.prev; dst[3] = 0u; }
+    for (uint32_t k = lane; k < n; k += 64) dst[4 + k] = w.buf[k];
+    w.prev = (int)c;
+  }
+}
+
+// append the set lanes' values; whenever PB_CHUNK candidates are buffered, emit a chunk
+PB_DI void append_candidates(const RenderParams& p, ChunkWriter& w, bool take, uint32_t value, int lane) {
+  const unsigned long long mask = __ballot(take);
+  if (mask == 0ull) return;
+  if (take) w.buf[w.count + lanes_below(mask)] = value;
+  w.count += (uint32_t)__builtin_popcountll(mask);
+  __syncthreads();
+  if (w.count >= PB_CHUNK) {
+    flush_chunk(p, w, PB_CHUNK, lane);
+    const uint32_t rest = w.count - PB_CHUNK;
+    uint32_t keep = 0;
+    if ((uint32_t)lane < rest) keep = w.buf[PB_CHUNK + lane];
+    __syncthreads();
+    if ((uint32_t)lane < rest) w.buf[lane] = keep;
+    w.count = rest;
+    __syncthreads();
+  }
+}
+
 template <bool COUNT>
-__global__ __launch_bounds__(64) void render_tiles_721_kernel(const RenderParams p) {
+__global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
+  __shared__ uint32_t buf[PB_CHUNK + 64];
   const int lane = threadIdx.x;
-  const int tile = blockIdx.x;
+  const int group = blockIdx.x;
+  const int nsub = p.ssaa * p.ssaa;
+  const int tile = group / nsub, sub = group % nsub;
+  const int si = sub / p.ssaa, sj = sub % p.ssaa;
   const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
   const int lx = lane & 7, ly = lane >> 3;
   const int ox = 8 * tx + lx, oy = 8 * tk + ly;             // output coordinates
   const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + ly;
   const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
-  double acc[3] = {0.0, 0.0, 0.0};
-  unsigned long long c_rays = 0, c_hit = 0, c_cand = 0, c_cyl = 0, c_valid = 0, c_gated = 0;
 
-  for (int si = 0; si < p.ssaa; ++si)
-    for (int sj = 0; sj < p.ssaa; ++sj) {
-      Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
-      r.active = r.active && in_image;
-      if (COUNT) { c_rays += in_image ? 1 : 0; c_hit += r.active ? 1 : 0; }
-      if (!r.active) r.maxd = -1.0f;     // every gate fails
-      if (__ballot(r.active) == 0ull) continue;
-      // side planes of the tile pyramid in sub-ray coordinates (wave-uniform)
-      const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
-      const float xl = (float)((p.x0 + 8 * tx) * p.ssaa) - half_w - 0.5f;
-      const float xr = (float)((p.x0 + 8 * tx + 7) * p.ssaa + p.ssaa - 1) - half_w + 0.5f;
-      const int ty0 = p.y0 + 8 * tk * p.strip_stride;
-      const float yt = (float)(ty0 * p.ssaa) - half_h - 0.5f;
-      const float yb = (float)((ty0 + 7) * p.ssaa + p.ssaa - 1) - half_h + 0.5f;
-      V3 pl[4];
-      pl[0] = normalize3(v3(p.focal, 0.0f, -xl));    // x/z >= xl/focal
-      pl[1] = normalize3(v3(-p.focal, 0.0f, xr));    // x/z <= xr/focal
-      pl[2] = normalize3(v3(0.0f, p.focal, -yt));
-      pl[3] = normalize3(v3(0.0f, -p.focal, yb));
+  Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
+  r.active = r.active && in_image;
+  // the root gate is a property of the ray alone (BeamRadiance.h:426-430 at the tree root)
+  const bool hit_scene = r.active;
+  r.active = r.active && box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd);
+  if (!r.active) r.maxd = -1.0f;     // every gate fails for this lane
+  float* rr = p.rays + (size_t)group * 8 * 64;
+  rr[0 * 64 + lane] = r.l.x; rr[1 * 64 + lane] = r.l.y; rr[2 * 64 + lane] = r.l.z;
+  rr[3 * 64 + lane] = r.dn.x; rr[4 * 64 + lane] = r.dn.y; rr[5 * 64 + lane] = r.dn.z;
+  rr[6 * 64 + lane] = r.maxd; rr[7 * 64 + lane] = 0.0f;
 
-      if (COUNT) {
-        // the pairs on which the reference calls HitCylinder: both gates pass, cylinder or not
-        if (box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd))
-          for (int sidx = 0; sidx < p.n_seg; ++sidx) {
-            const SegFrame& f = p.frames[sidx];
-            c_gated += box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd) ? 1 : 0;
-          }
-      }
-      for (int base = 0; base < p.n_seg; base += 64) {
-        const int s = base + lane;
-        bool touch = false;
-        if (s < p.n_seg) touch = capsule_touches_pyramid(p.capA[s], p.capB[s], pl);
-        unsigned long long mask = __ballot(touch);
-        while (mask) {
-          const int bit = __builtin_ctzll(mask);
-          mask &= mask - 1;
-          const int sidx = __builtin_amdgcn_readfirstlane(base + bit);
-          const SegFrame& f = p.frames[sidx];
-          bool gated = false;
-          const int res = eval_pair_721(f, r, p.root, p.extinction_c, acc, gated);
-          if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
-        }
+  ChunkWriter w;
+  w.buf = buf; w.count = 0; w.prev = -1; w.group = group;
+  unsigned long long c_gated = 0;
+  if (__ballot(r.active) != 0ull) {
+    // side planes of the tile pyramid in sub-ray coordinates (wave-uniform)
+    const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
+    const float xl = (float)((p.x0 + 8 * tx) * p.ssaa) - half_w - 0.5f;
+    const float xr = (float)((p.x0 + 8 * tx + 7) * p.ssaa + p.ssaa - 1) - half_w + 0.5f;
+    const int ty0 = p.y0 + 8 * tk * p.strip_stride;
+    const float yt = (float)(ty0 * p.ssaa) - half_h - 0.5f;
+    const float yb = (float)((ty0 + 7) * p.ssaa + p.ssaa - 1) - half_h + 0.5f;
+    V3 pl[4];
+    pl[0] = normalize3(v3(p.focal, 0.0f, -xl));    // x/z >= xl/focal
+    pl[1] = normalize3(v3(-p.focal, 0.0f, xr));    // x/z <= xr/focal
+    pl[2] = normalize3(v3(0.0f, p.focal, -yt));
+    pl[3] = normalize3(v3(0.0f, -p.focal, yb));
+    if (COUNT) {
+      // the pairs on which the reference calls HitCylinder: both gates pass, cylinder or not
+      for (int sidx = 0; sidx < p.n_seg; ++sidx) {
+        const SegFrame& f = p.frames[sidx];
+        c_gated += box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd) ? 1 : 0;
       }
     }
-
-  if (in_image) {
-    float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
-    const double inv = (double)p.ssaa;
-    o[0] = (float)(acc[0] / inv);
-    o[1] = (float)(acc[1] / inv);
-    o[2] = (float)(acc[2] / inv);
+    for (int base = 0; base < p.n_seg; base += 64) {
+      const int s = base + lane;
+      bool touch = false;
+      if (s < p.n_seg) touch = capsule_touches_pyramid(p.capA[s], p.capB[s], pl);
+      append_candidates(p, w, touch, (uint32_t)s, lane);
+    }
+    if (w.count > 0) flush_chunk(p, w, w.count, lane);
   }
+  if (lane == 0) p.group_last[group] = w.prev;
   if (COUNT) {
-    unsigned long long v[6] = {c_rays, c_hit, c_cand, c_cyl, c_valid, c_gated};
-    const int slot[6] = {PB_CNT_RAYS, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_GATED};
-    for (int k = 0; k < 6; ++k) {
+    unsigned long long v[3] = {in_image ? 1ull : 0ull, hit_scene ? 1ull : 0ull, c_gated};
+    const int slot[3] = {PB_CNT_RAYS, PB_CNT_RAYS_HIT, PB_CNT_GATED};
+    for (int k = 0; k < 3; ++k) {
       unsigned long long x = v[k];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
       if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
@@ -232,14 +277,94 @@ __global__ __launch_bounds__(64) void render_tiles_721_kernel(const RenderParams
   }
 }
 
+template <bool COUNT>
+__global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
+  const int lane = threadIdx.x;
+  unsigned long long c_cand = 0, c_cyl = 0, c_valid = 0;
+  const uint32_t produced = p.ctrl[0];
+  const uint32_t n_chunks = produced < (uint32_t)p.chunk_capacity ? produced : (uint32_t)p.chunk_capacity;
+  while (true) {
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(&p.ctrl[1], 1u);
+    c = __builtin_amdgcn_readfirstlane(c);
+    if (c >= n_chunks) break;              // every wave reaches this: the counter only grows
+    const uint32_t* ch = p.chunks + (size_t)c * PB_CHUNK_WORDS;
+    const int group = (int)ch[0];
+    const int n = (int)ch[1];
+    const float* rr = p.rays + (size_t)group * 8 * 64;
+    Ray r;
+    r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+    r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
+    r.maxd = rr[6 * 64 + lane];
+    r.active = r.maxd >= 0.0f;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < n; ++k) {
+      const int sidx = (int)ch[4 + k];
+      const SegFrame& f = p.frames[sidx];
+      const int res = eval_pair_721(f, r, p.extinction_c, acc);
+      if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
+    }
+    double* part = p.partials + (size_t)c * 3 * 64;
+    part[0 * 64 + lane] = acc[0]; part[1 * 64 + lane] = acc[1]; part[2 * 64 + lane] = acc[2];
+  }
+  if (COUNT) {
+    unsigned long long v[3] = {c_cand, c_cyl, c_valid};
+    const int slot[3] = {PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID};
+    for (int k = 0; k < 3; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void reduce_kernel(const RenderParams p) {
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int nsub = p.ssaa * p.ssaa;
+  const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
+  const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int sub = 0; sub < nsub; ++sub) {
+    int c = p.group_last[tile * nsub + sub];
+    while (c >= 0) {
+      const double* part = p.partials + (size_t)c * 3 * 64;
+      acc[0] = acc[0] + part[0 * 64 + lane];
+      acc[1] = acc[1] + part[1 * 64 + lane];
+      acc[2] = acc[2] + part[2 * 64 + lane];
+      c = (int)p.chunks[(size_t)c * PB_CHUNK_WORDS + 2];
+    }
+  }
+  if (ox < p.out_w && oy < p.out_h) {
+    float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
+    const double inv = (double)p.ssaa;        // skeleton.cpp:361: current / (double) SSAA
+    o[0] = (float)(acc[0] / inv);
+    o[1] = (float)(acc[1] / inv);
+    o[2] = (float)(acc[2] / inv);
+  }
+}
+
 }  // namespace
 
-int pb_launch_render(const RenderParams& p, int mode, bool count, hipStream_t s) {
+int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
+  (void)mode;
+  const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
+  if (groups <= 0) return PB_OK;
+  if (count) hipLaunchKernelGGL(cull_kernel<true>, dim3(groups), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(cull_kernel<false>, dim3(groups), dim3(64), 0, s, p);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}
+
+int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s) {
   if (mode != PB_MODE_721) { pb_set_error("pb_render: only PB_MODE_721 is implemented"); return PB_ERR_ARG; }
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
-  if (count) hipLaunchKernelGGL(render_tiles_721_kernel<true>, dim3(tiles), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL(render_tiles_721_kernel<false>, dim3(tiles), dim3(64), 0, s, p);
+  int waves = p.chunk_capacity < PB_EVAL_WAVES ? p.chunk_capacity : PB_EVAL_WAVES;
+  if (waves < 1) waves = 1;
+  if (count) hipLaunchKernelGGL(eval_kernel<true>, dim3(waves), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(eval_kernel<false>, dim3(waves), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(reduce_kernel, dim3(tiles), dim3(64), 0, s, p);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }
