@@ -1283,6 +1283,105 @@ static void add_counters(orc_counters& a, const orc_counters& b) {
   a.cyl_calls += b.cyl_calls; a.cyl_true += b.cyl_true; a.valid_hits += b.valid_hits;
 }
 
+// ---- CPU twin of the GPU's linear BVH (keys, stable sort, Karras hierarchy, refit) ----
+static uint64_t expand16(uint32_t v) {
+  uint64_t x = v & 0xFFFFu;
+  x = (x | (x << 16)) & 0x000000FF0000FFull;
+  x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+static int lbvh_delta(const std::vector<uint64_t>& keys, int i, int j) {
+  const int n = (int)keys.size();
+  if (j < 0 || j >= n) return -1;
+  const uint64_t x = keys[i] ^ keys[j];
+  if (x == 0ull) return 64 + __builtin_clz((uint32_t)(i ^ j));
+  return __builtin_clzll(x);
+}
+int orc_lbvh(const pb_segment* segs, int n, uint64_t* keys_out, uint32_t* perm_out, pb_node* nodes_out) {
+  if (n < 2) return 0;
+  std::vector<float> mid(3 * (size_t)n);
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const float m = (segs[i].start[k] + segs[i].end[k]) * 0.5f;
+      mid[3 * (size_t)i + k] = m;
+      lo[k] = std::fmin(lo[k], m); hi[k] = std::fmax(hi[k], m);
+    }
+  std::vector<uint64_t> key(n);
+  for (int i = 0; i < n; ++i) {
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+      const float ext = hi[k] - lo[k];
+      const float scale = (ext > 0.0f) ? (65535.0f / ext) : 0.0f;
+      float t = (mid[3 * (size_t)i + k] - lo[k]) * scale;
+      t = std::fmin(std::fmax(t, 0.0f), 65535.0f);
+      q[k] = (uint32_t)t;
+    }
+    key[i] = (expand16(q[0]) << 2) | (expand16(q[1]) << 1) | expand16(q[2]);
+  }
+  std::vector<uint32_t> perm(n);
+  for (int i = 0; i < n; ++i) perm[i] = (uint32_t)i;
+  std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+  std::vector<uint64_t> keys(n);
+  for (int i = 0; i < n; ++i) keys[i] = key[perm[i]];
+  std::vector<int> left(n - 1), right(n - 1), parent(n - 1, -1), parent_leaf(n, -1);
+  for (int i = 0; i < n - 1; ++i) {
+    const int d = (lbvh_delta(keys, i, i + 1) - lbvh_delta(keys, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+      if (lbvh_delta(keys, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(keys, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+      if (lbvh_delta(keys, i, i + (s + t) * d) > dnode) s += t;
+      if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int a = std::min(i, j), b = std::max(i, j);
+    left[i] = (a == gamma) ? ~gamma : gamma;
+    right[i] = (b == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    if (left[i] >= 0) parent[left[i]] = i; else parent_leaf[~left[i]] = i;
+    if (right[i] >= 0) parent[right[i]] = i; else parent_leaf[~right[i]] = i;
+  }
+  // boxes: leaves are padded capsule bounds, inner nodes the union of their children (post-order)
+  std::vector<float> leaf_box(6 * (size_t)n), node_box(6 * ((size_t)n - 1));
+  for (int i = 0; i < n; ++i) {
+    const pb_segment& sg = segs[perm[i]];
+    const float pad = sg.radius * 1.001f + 1e-5f;
+    for (int k = 0; k < 3; ++k) {
+      leaf_box[6 * (size_t)i + k] = std::fmin(sg.start[k], sg.end[k]) - pad;
+      leaf_box[6 * (size_t)i + 3 + k] = std::fmax(sg.start[k], sg.end[k]) + pad;
+    }
+  }
+  std::vector<int> order; order.reserve(n - 1);
+  { std::vector<int> st; st.push_back(0);
+    while (!st.empty()) { int v = st.back(); st.pop_back(); order.push_back(v);
+      if (left[v] >= 0) st.push_back(left[v]); if (right[v] >= 0) st.push_back(right[v]); } }
+  for (int q = (int)order.size() - 1; q >= 0; --q) {
+    const int v = order[q];
+    const float* a = left[v] >= 0 ? &node_box[6 * (size_t)left[v]] : &leaf_box[6 * (size_t)(~left[v])];
+    const float* b = right[v] >= 0 ? &node_box[6 * (size_t)right[v]] : &leaf_box[6 * (size_t)(~right[v])];
+    for (int k = 0; k < 3; ++k) {
+      node_box[6 * (size_t)v + k] = std::fmin(a[k], b[k]);
+      node_box[6 * (size_t)v + 3 + k] = std::fmax(a[3 + k], b[3 + k]);
+    }
+  }
+  if ((int)order.size() != n - 1) return -1;   // the hierarchy must reach every inner node exactly once
+  for (int i = 0; i < n; ++i) { if (keys_out) keys_out[i] = keys[i]; if (perm_out) perm_out[i] = perm[i]; }
+  if (nodes_out)
+    for (int i = 0; i < n - 1; ++i) {
+      for (int k = 0; k < 3; ++k) { nodes_out[i].lo[k] = node_box[6 * (size_t)i + k]; nodes_out[i].hi[k] = node_box[6 * (size_t)i + 3 + k]; }
+      nodes_out[i].left = left[i]; nodes_out[i].right = right[i];
+    }
+  return n;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -79,6 +79,8 @@ int  orc_render_segments_strided(const pb_control* control, const float* tri_xyz
                          const float* grid_sigma, int side, const pb_segment* segs, int n,
                          const float root_lo[3], const float root_hi[3], int x0, int y0, int w, int h,
                          int step_x, int step_y, int mode, double* rgb, orc_counters* counters, int threads);
+/* CPU twin of the GPU's linear BVH: Morton keys (sorted), permutation, inner nodes. */
+int  orc_lbvh(const pb_segment* segs, int n, uint64_t* keys_out, uint32_t* perm_out, pb_node* nodes_out);
 int  orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -98,7 +98,9 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
   if (!ctx->have_segments) { pb_set_error("pb_render: no segment set (pb_upload_segments / pb_emit_beams)"); return PB_ERR_STATE; }
   if (mode != PB_MODE_721 && mode != PB_MODE_73HET) { pb_set_error("pb_render: mode must be PB_MODE_721 or PB_MODE_73HET"); return PB_ERR_ARG; }
-  if (use_lbvh) { pb_set_error("pb_render: pb_build_lbvh has not been called"); return PB_ERR_STATE; }
+  if (use_lbvh && (ctx->lb_n < 0 || ctx->lb_version != ctx->segs_version)) {
+    pb_set_error("pb_render: pb_build_lbvh has not been called for this segment set"); return PB_ERR_STATE;
+  }
   if (ctx->frame_mode != mode) {
     int rc = pb_prepare_frames(ctx, mode, s);
     if (rc != PB_OK) return rc;
@@ -114,6 +116,10 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.x0 = x0; p.y0 = y0; p.out_w = out_w; p.out_h = out_h; p.strip_stride = strip_stride;
   p.tiles_x = (out_w + 7) / 8; p.tiles_y = (out_h + 7) / 8;
   p.out = d_out;
+  if (use_lbvh && ctx->lb_n >= 2) {
+    p.lbvh_nodes = ctx->lb_nodes; p.lbvh_sA = ctx->lb_sA; p.lbvh_sB = ctx->lb_sB; p.lbvh_perm = ctx->lb_perm;
+    p.lbvh_n = ctx->lb_n;
+  }
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
 
@@ -217,7 +223,8 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
                   ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_rays, ctx->d_group_last,
-                  ctx->d_chunks, ctx->d_partials, ctx->d_ctrl};
+                  ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
+                  ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -350,14 +357,19 @@ int pb_beam_counts(pb_ctx* ctx, int* n_const, int* n_scatt) {
 }
 
 int pb_build_lbvh(pb_ctx* ctx) {
-  (void)ctx;
-  pb_set_error("pb_build_lbvh: not implemented yet");
-  return PB_ERR_STATE;
+  if (!ctx) { pb_set_error("pb_build_lbvh: null context"); return PB_ERR_ARG; }
+  if (!ctx->have_segments) { pb_set_error("pb_build_lbvh: no segment set"); return PB_ERR_STATE; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  return pb_lbvh_build(ctx);
 }
+
 int pb_download_lbvh(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes) {
-  (void)ctx; (void)keys; (void)perm; (void)nodes;
-  pb_set_error("pb_download_lbvh: not implemented yet");
-  return PB_ERR_STATE;
+  if (!ctx) { pb_set_error("pb_download_lbvh: null context"); return PB_ERR_ARG; }
+  if (ctx->lb_n < 0 || ctx->lb_version != ctx->segs_version) { pb_set_error("pb_download_lbvh: pb_build_lbvh has not been called for this segment set"); return PB_ERR_STATE; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  return pb_lbvh_download(ctx, keys, perm, nodes);
 }
 
 int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh, float* d_rgb_out, void* stream) {

@@ -50,6 +50,15 @@ struct __attribute__((aligned(64))) SegFrame {
 };
 static_assert(sizeof(SegFrame) == 192, "SegFrame layout");
 
+// LBVH internal node as the tile traversal reads it: both child boxes inline, 64 B.
+// child >= 0: internal node index; child < 0: leaf, ~child = position in Morton order.
+struct __attribute__((aligned(64))) LbvhNode {
+  float lo0[3], hi0[3], lo1[3], hi1[3];
+  int child0, child1;
+  int pad[2];
+};
+static_assert(sizeof(LbvhNode) == 64, "LbvhNode layout");
+
 // Gate box of the tree root (BeamRadiance.h:426-430 applied to `root`).
 struct GateBox {
   float lo[3], hi[3], cand[3];
@@ -79,14 +88,18 @@ struct RenderParams {
   double* partials;         // [chunk_capacity][3][64]
   uint32_t* ctrl;           // [0] chunks produced, [1] chunks taken by eval waves
   int chunk_capacity;
-  // LBVH (null: scan all segments)
-  const void* lbvh_nodes;
+  // LBVH (lbvh_n < 2: scan all segments)
+  const LbvhNode* lbvh_nodes;
+  const float4* lbvh_sA;    // capsules in Morton order
+  const float4* lbvh_sB;
   const uint32_t* lbvh_perm;
+  int lbvh_n;
 };
 
 constexpr int PB_CHUNK = 124;          // candidates per chunk
 constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 512 B
-constexpr int PB_EVAL_WAVES = 256 * 32; // one resident wave slot per SIMD lane group of the chip
+constexpr int PB_EVAL_WAVES = 256 * 32;
+constexpr int PB_STACK_CAP = 2048;     // LBVH traversal stack entries per wave (plus 128 of slack) // one resident wave slot per SIMD lane group of the chip
 
 enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_N };
 
@@ -119,6 +132,18 @@ struct pb_ctx {
   // output staging for the host-pointer render
   float* d_out = nullptr;
   size_t out_floats = 0;
+  // LBVH of the segment set (pb_lbvh.hip)
+  uint64_t* lb_keys = nullptr;
+  uint32_t* lb_perm = nullptr;
+  LbvhNode* lb_nodes = nullptr;
+  float4* lb_sA = nullptr;
+  float4* lb_sB = nullptr;
+  int* lb_left = nullptr;
+  int* lb_right = nullptr;
+  float* lb_node_box = nullptr;
+  float* lb_leaf_box = nullptr;
+  int lb_n = -1;
+  unsigned long long lb_version = ~0ull;
   // frame workspace
   float* d_rays = nullptr;
   int* d_group_last = nullptr;
@@ -139,6 +164,8 @@ int pb_ensure_segment_capacity(pb_ctx* ctx, int n);
 int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s);
 int pb_default_mode(const pb_ctx* ctx);
 int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed);
+int pb_lbvh_build(pb_ctx* ctx);
+int pb_lbvh_download(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes);
 
 #define PB_HIP(call)                                                                         \
   do {                                                                                       \

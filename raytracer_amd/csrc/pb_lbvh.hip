@@ -1,0 +1,377 @@
+// BuildTree (CastPhotons.h:800-1126) replacement: a linear BVH over the segment
+// capsules, built on the GPU.
+//   1. bounds of the capsule midpoints (block reduce + ordered-uint atomics)
+//   2. 48-bit Morton key per segment (16 bits per axis), payload = segment index
+//   3. LSD radix sort, 8-bit digits, 6 passes: per-block digit histograms in LDS,
+//      a device-wide exclusive scan of (digit, block) counts, and a stable
+//      scatter whose in-block ranks come from wave match masks and per-wave LDS
+//      counters (no atomics on the rank path, so the permutation is stable)
+//   4. Karras (2012) hierarchy: one lane per internal node, ties between equal
+//      keys broken by sorted position
+//   5. bottom-up refit with one arrival counter per internal node
+//   6. packing: each internal node record carries both child boxes, leaves are
+//      the sorted capsules
+// The reference's tree decides nothing about the result except through the gate
+// boxes stored with each segment; this structure only finds candidates.
+#include <cstring>
+#include <vector>
+
+#include "pb_internal.h"
+#include "pb_scan.h"
+
+namespace {
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+constexpr int MORTON_BITS = 16;   // per axis
+constexpr int SORT_PASSES = 6;    // 48 bits / 8
+
+// order-preserving map float -> uint for atomicMin/atomicMax
+PB_DI uint32_t float_ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+PB_HDI float ord_float(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  float f;
+  memcpy(&f, &u, sizeof(f));
+  return f;
+}
+
+__global__ __launch_bounds__(256) void bounds_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
+                                                    int n, uint32_t* __restrict__ bounds6) {
+  float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+  float hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 a = capA[i], b = capB[i];
+    const float m[3] = {(a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f, (a.z + b.z) * 0.5f};
+    for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], m[k]); hi[k] = fmaxf(hi[k], m[k]); }
+  }
+  for (int k = 0; k < 3; ++k)
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_down(lo[k], off, 64));
+      hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; ++k) {
+      atomicMin(&bounds6[k], float_ord(lo[k]));
+      atomicMax(&bounds6[3 + k], float_ord(hi[k]));
+    }
+}
+
+PB_HDI uint64_t expand16(uint32_t v) {   // bit k of v -> bit 3k
+  uint64_t x = v & 0xFFFFu;
+  x = (x | (x << 16)) & 0x000000FF0000FFull;
+  x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
+                                                    int n, const uint32_t* __restrict__ bounds6,
+                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = capA[i], b = capB[i];
+  const float m[3] = {(a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f, (a.z + b.z) * 0.5f};
+  uint32_t q[3];
+  for (int k = 0; k < 3; ++k) {
+    const float lo = ord_float(bounds6[k]), hi = ord_float(bounds6[3 + k]);
+    const float ext = hi - lo;
+    const float scale = (ext > 0.0f) ? (65535.0f / ext) : 0.0f;
+    float t = (m[k] - lo) * scale;
+    t = fminf(fmaxf(t, 0.0f), 65535.0f);
+    q[k] = (uint32_t)t;
+  }
+  keys[i] = (expand16(q[0]) << 2) | (expand16(q[1]) << 1) | expand16(q[2]);
+  vals[i] = (uint32_t)i;
+}
+
+// ---- radix sort ----
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift,
+                                                                int n_blocks, uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * SORT_TILE;
+#pragma unroll
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    const int i = base + k * SORT_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  ghist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// lanes of the wave holding the same 8-bit digit (invalid lanes match nobody)
+PB_DI unsigned long long match_digit(uint32_t digit, bool valid) {
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (digit >> b) & 1u;
+    const unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys_in,
+                                                                   const uint32_t* __restrict__ vals_in, int n,
+                                                                   int shift, int n_blocks,
+                                                                   const uint32_t* __restrict__ gscan,
+                                                                   uint64_t* __restrict__ keys_out,
+                                                                   uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t cnt[SORT_WAVES][256];
+  __shared__ uint32_t goff[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
+  goff[threadIdx.x] = gscan[(size_t)threadIdx.x * n_blocks + blockIdx.x];
+  __syncthreads();
+  // wave w owns the contiguous keys [base + w*64*ITEMS, +64*ITEMS): order (wave, item, lane) = input order
+  const int wbase = blockIdx.x * SORT_TILE + wave * 64 * SORT_ITEMS;
+  uint64_t key[SORT_ITEMS];
+  uint32_t val[SORT_ITEMS], rank[SORT_ITEMS];
+#pragma unroll
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    const int i = wbase + k * 64 + lane;
+    const bool valid = i < n;
+    key[k] = valid ? keys_in[i] : 0ull;
+    val[k] = valid ? vals_in[i] : 0u;
+    const uint32_t digit = (uint32_t)(key[k] >> shift) & 255u;
+    const unsigned long long peers = match_digit(digit, valid);
+    const unsigned long long below = peers & ((1ull << lane) - 1ull);
+    uint32_t prior = 0;
+    if (valid) prior = cnt[wave][digit];
+    rank[k] = prior + (uint32_t)__builtin_popcountll(below);
+    __syncthreads();   // every peer has read the running count before its leader bumps it
+    if (valid && below == 0ull) cnt[wave][digit] = prior + (uint32_t)__builtin_popcountll(peers);
+    __syncthreads();
+  }
+  // exclusive prefix of the per-wave counts over the waves of the block, per digit
+  {
+    uint32_t run = 0;
+    for (int w = 0; w < SORT_WAVES; ++w) { const uint32_t c = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += c; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SORT_ITEMS; ++k) {
+    const int i = wbase + k * 64 + lane;
+    if (i < n) {
+      const uint32_t digit = (uint32_t)(key[k] >> shift) & 255u;
+      const uint32_t dst = goff[digit] + cnt[wave][digit] + rank[k];
+      keys_out[dst] = key[k];
+      vals_out[dst] = val[k];
+    }
+  }
+}
+
+// ---- hierarchy ----
+PB_DI int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t x = keys[i] ^ keys[j];
+  if (x == 0ull) return 64 + __builtin_clz((uint32_t)(i ^ j));
+  return __builtin_clzll(x);
+}
+
+// Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees" (2012), alg. 4.
+// Children: >= 0 internal node, < 0 leaf ~child (sorted position).
+__global__ __launch_bounds__(256) void karras_kernel(const uint64_t* __restrict__ keys, int n, int* __restrict__ left,
+                                                    int* __restrict__ right, int* __restrict__ parent_internal,
+                                                    int* __restrict__ parent_leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t == 1) break;
+  }
+  const int gamma = i + s * d + (d < 0 ? -1 : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  const int lc = (lo == gamma) ? ~gamma : gamma;
+  const int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+  left[i] = lc; right[i] = rc;
+  if (lc >= 0) parent_internal[lc] = i; else parent_leaf[~lc] = i;
+  if (rc >= 0) parent_internal[rc] = i; else parent_leaf[~rc] = i;
+  if (i == 0) parent_internal[0] = -1;
+}
+
+// capsule bounds with the slack the tile test uses
+PB_DI void capsule_box(float4 a, float4 b, float lo[3], float hi[3]) {
+  const float pad = a.w * 1.001f + 1e-5f;
+  lo[0] = fminf(a.x, b.x) - pad; lo[1] = fminf(a.y, b.y) - pad; lo[2] = fminf(a.z, b.z) - pad;
+  hi[0] = fmaxf(a.x, b.x) + pad; hi[1] = fmaxf(a.y, b.y) + pad; hi[2] = fmaxf(a.z, b.z) + pad;
+}
+
+__global__ __launch_bounds__(256) void refit_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
+                                                   const uint32_t* __restrict__ perm, int n,
+                                                   const int* __restrict__ left, const int* __restrict__ right,
+                                                   const int* __restrict__ parent_internal,
+                                                   const int* __restrict__ parent_leaf, float* leaf_box,
+                                                   float* node_box, uint32_t* arrivals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = perm[i];
+  float lo[3], hi[3];
+  capsule_box(capA[s], capB[s], lo, hi);
+  for (int k = 0; k < 3; ++k) { leaf_box[(size_t)i * 6 + k] = lo[k]; leaf_box[(size_t)i * 6 + 3 + k] = hi[k]; }
+  int node = parent_leaf[i];
+  while (node >= 0) {
+    __threadfence();                                  // my child box is visible before I announce it
+    if (atomicAdd(&arrivals[node], 1u) == 0u) return; // the second arrival goes on
+    __threadfence();
+    const int lc = left[node], rc = right[node];
+    const float* a = (lc >= 0) ? (node_box + (size_t)lc * 6) : (leaf_box + (size_t)(~lc) * 6);
+    const float* b = (rc >= 0) ? (node_box + (size_t)rc * 6) : (leaf_box + (size_t)(~rc) * 6);
+    float* o = node_box + (size_t)node * 6;
+    for (int k = 0; k < 3; ++k) {
+      const float al = a[k], bl = b[k], ah = a[3 + k], bh = b[3 + k];
+      o[k] = fminf(al, bl);
+      o[3 + k] = fmaxf(ah, bh);
+    }
+    node = parent_internal[node];
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
+                                                  const uint32_t* __restrict__ perm, int n,
+                                                  const int* __restrict__ left, const int* __restrict__ right,
+                                                  const float* __restrict__ leaf_box, const float* __restrict__ node_box,
+                                                  LbvhNode* __restrict__ nodes, float4* __restrict__ sA,
+                                                  float4* __restrict__ sB) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const uint32_t s = perm[i]; sA[i] = capA[s]; sB[i] = capB[s]; }
+  if (i < n - 1) {
+    const int lc = left[i], rc = right[i];
+    const float* a = (lc >= 0) ? (node_box + (size_t)lc * 6) : (leaf_box + (size_t)(~lc) * 6);
+    const float* b = (rc >= 0) ? (node_box + (size_t)rc * 6) : (leaf_box + (size_t)(~rc) * 6);
+    LbvhNode nd;
+    for (int k = 0; k < 3; ++k) { nd.lo0[k] = a[k]; nd.hi0[k] = a[3 + k]; nd.lo1[k] = b[k]; nd.hi1[k] = b[3 + k]; }
+    nd.child0 = lc; nd.child1 = rc; nd.pad[0] = nd.pad[1] = 0;
+    nodes[i] = nd;
+  }
+}
+
+struct Scratch {
+  void* p = nullptr;
+  ~Scratch() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+int pb_lbvh_build(pb_ctx* ctx) {
+  const int n = ctx->n_seg;
+  hipStream_t s = ctx->stream;
+  PB_HIP(hipEventRecord(ctx->ev[4], s));
+  // persistent results
+  void* olds[] = {ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes, ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right,
+                  ctx->lb_node_box, ctx->lb_leaf_box};
+  for (void* o : olds) if (o) PB_HIP(hipFree(o));
+  ctx->lb_keys = nullptr; ctx->lb_perm = nullptr; ctx->lb_nodes = nullptr; ctx->lb_sA = nullptr; ctx->lb_sB = nullptr;
+  ctx->lb_left = nullptr; ctx->lb_right = nullptr; ctx->lb_node_box = nullptr; ctx->lb_leaf_box = nullptr;
+  ctx->lb_n = 0;
+  if (n < 2) {   // nothing to build: the renderer scans the (at most one) segment
+    ctx->lb_n = n; ctx->lb_version = ctx->segs_version;
+    PB_HIP(hipEventRecord(ctx->ev[5], s));
+    ctx->ev_valid[2] = true;
+    return PB_OK;
+  }
+  const size_t N = (size_t)n;
+  PB_HIP(hipMalloc(&ctx->lb_keys, sizeof(uint64_t) * N));
+  PB_HIP(hipMalloc(&ctx->lb_perm, sizeof(uint32_t) * N));
+  PB_HIP(hipMalloc(&ctx->lb_nodes, sizeof(LbvhNode) * (N - 1)));
+  PB_HIP(hipMalloc(&ctx->lb_sA, sizeof(float4) * N));
+  PB_HIP(hipMalloc(&ctx->lb_sB, sizeof(float4) * N));
+  PB_HIP(hipMalloc(&ctx->lb_left, sizeof(int) * (N - 1)));
+  PB_HIP(hipMalloc(&ctx->lb_right, sizeof(int) * (N - 1)));
+  PB_HIP(hipMalloc(&ctx->lb_node_box, sizeof(float) * 6 * (N - 1)));
+  PB_HIP(hipMalloc(&ctx->lb_leaf_box, sizeof(float) * 6 * N));
+
+  const int n_blocks = (n + SORT_TILE - 1) / SORT_TILE;
+  const size_t hist_words = (size_t)256 * n_blocks;
+  const size_t scan_words = pb_scan_tmp_words((int)hist_words);
+  Scratch sc;
+  // keys2[N] (u64) | vals2[N] | hist[256*nb] | scan tmp | total | parents (2N) | arrivals (N) | bounds (8)
+  const size_t bytes = sizeof(uint64_t) * N + sizeof(uint32_t) * (N + hist_words + scan_words + 8 + 2 * N + N + 8);
+  PB_HIP(hipMalloc(&sc.p, bytes));
+  uint64_t* keys2 = (uint64_t*)sc.p;
+  uint32_t* vals2 = (uint32_t*)(keys2 + N);
+  uint32_t* hist = vals2 + N;
+  uint32_t* scan_tmp = hist + hist_words;
+  uint32_t* total = scan_tmp + scan_words;
+  int* parent_internal = (int*)(total + 8);
+  int* parent_leaf = parent_internal + N;
+  uint32_t* arrivals = (uint32_t*)(parent_leaf + N);
+  uint32_t* bounds = arrivals + N;
+
+  const uint32_t init_bounds[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+  PB_HIP(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
+  PB_HIP(hipMemsetAsync(arrivals, 0, sizeof(uint32_t) * N, s));
+  int bblocks = (n + 255) / 256;
+  if (bblocks > 1024) bblocks = 1024;
+  hipLaunchKernelGGL(bounds_kernel, dim3(bblocks), dim3(256), 0, s, ctx->d_capA, ctx->d_capB, n, bounds);
+  hipLaunchKernelGGL(morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->d_capA, ctx->d_capB, n, bounds,
+                     ctx->lb_keys, ctx->lb_perm);
+  PB_HIP(hipGetLastError());
+  uint64_t* kin = ctx->lb_keys; uint32_t* vin = ctx->lb_perm;
+  uint64_t* kout = keys2; uint32_t* vout = vals2;
+  for (int pass = 0; pass < SORT_PASSES; ++pass) {
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, n, shift, n_blocks, hist);
+    int rc = pb_exclusive_scan_u32(hist, hist, (int)hist_words, total, scan_tmp, s);
+    if (rc != PB_OK) return rc;
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift, n_blocks, hist,
+                       kout, vout);
+    PB_HIP(hipGetLastError());
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    uint32_t* tv = vin; vin = vout; vout = tv;
+  }
+  // SORT_PASSES is even: the sorted data is back in lb_keys / lb_perm
+  static_assert(SORT_PASSES % 2 == 0, "sorted keys must end in the persistent buffers");
+  hipLaunchKernelGGL(karras_kernel, dim3((n - 1 + 255) / 256), dim3(256), 0, s, ctx->lb_keys, n, ctx->lb_left,
+                     ctx->lb_right, parent_internal, parent_leaf);
+  hipLaunchKernelGGL(refit_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->d_capA, ctx->d_capB, ctx->lb_perm, n,
+                     ctx->lb_left, ctx->lb_right, parent_internal, parent_leaf, ctx->lb_leaf_box, ctx->lb_node_box,
+                     arrivals);
+  hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->d_capA, ctx->d_capB, ctx->lb_perm, n,
+                     ctx->lb_left, ctx->lb_right, ctx->lb_leaf_box, ctx->lb_node_box, ctx->lb_nodes, ctx->lb_sA,
+                     ctx->lb_sB);
+  PB_HIP(hipGetLastError());
+  PB_HIP(hipEventRecord(ctx->ev[5], s));
+  ctx->ev_valid[2] = true;
+  PB_HIP(hipStreamSynchronize(s));
+  ctx->lb_n = n;
+  ctx->lb_version = ctx->segs_version;
+  return PB_OK;
+}
+
+int pb_lbvh_download(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes) {
+  const int n = ctx->lb_n;
+  if (n < 2) return PB_OK;
+  PB_HIP(hipDeviceSynchronize());
+  if (keys) PB_HIP(hipMemcpy(keys, ctx->lb_keys, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+  if (perm) PB_HIP(hipMemcpy(perm, ctx->lb_perm, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+  if (nodes) {
+    std::vector<int> l((size_t)n - 1), r((size_t)n - 1);
+    std::vector<float> box(6 * ((size_t)n - 1));
+    PB_HIP(hipMemcpy(l.data(), ctx->lb_left, sizeof(int) * l.size(), hipMemcpyDeviceToHost));
+    PB_HIP(hipMemcpy(r.data(), ctx->lb_right, sizeof(int) * r.size(), hipMemcpyDeviceToHost));
+    PB_HIP(hipMemcpy(box.data(), ctx->lb_node_box, sizeof(float) * box.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i + 1 < (size_t)n; ++i) {
+      for (int k = 0; k < 3; ++k) { nodes[i].lo[k] = box[i * 6 + k]; nodes[i].hi[k] = box[i * 6 + 3 + k]; }
+      nodes[i].left = l[i]; nodes[i].right = r[i];
+    }
+  }
+  return PB_OK;
+}

@@ -209,9 +209,22 @@ PB_DI void append_candidates(const RenderParams& p, ChunkWriter& w, bool take, u
   }
 }
 
-template <bool COUNT>
+// Conservative test of an (already padded) box against the four side planes of the tile pyramid.
+PB_DI bool box_touches_pyramid(const float lo[3], const float hi[3], const V3 pl[4]) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float d = pl[k].x * (pl[k].x >= 0 ? hi[0] : lo[0]) + pl[k].y * (pl[k].y >= 0 ? hi[1] : lo[1]) +
+                    pl[k].z * (pl[k].z >= 0 ? hi[2] : lo[2]);
+    ok = ok && (d >= 0.0f);
+  }
+  return ok;
+}
+
+template <bool COUNT, bool LBVH>
 __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   __shared__ uint32_t buf[PB_CHUNK + 64];
+  __shared__ int stack[LBVH ? (PB_STACK_CAP + 128) : 1];
   const int lane = threadIdx.x;
   const int group = blockIdx.x;
   const int nsub = p.ssaa * p.ssaa;
@@ -257,11 +270,47 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
         c_gated += box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd) ? 1 : 0;
       }
     }
-    for (int base = 0; base < p.n_seg; base += 64) {
-      const int s = base + lane;
-      bool touch = false;
-      if (s < p.n_seg) touch = capsule_touches_pyramid(p.capA[s], p.capB[s], pl);
-      append_candidates(p, w, touch, (uint32_t)s, lane);
+    if (LBVH) {
+      // Wave-cooperative traversal: up to 64 nodes are popped per step, one per lane; a lane tests both
+      // child boxes of its node, inner children are pushed with ballot compaction, leaf children are
+      // tested as capsules and appended to the candidate list.
+      int top = 1;
+      if (lane == 0) stack[0] = 0;
+      __syncthreads();
+      while (top > 0) {
+        int k = top < 64 ? top : 64;
+        if (top + k > PB_STACK_CAP) { k = PB_STACK_CAP - top; if (k < 1) k = 1; }   // keep pushes inside the slack
+        const int node = (lane < k) ? stack[top - k + lane] : -1;
+        top -= k;
+        __syncthreads();
+        bool in0 = false, in1 = false, lf0 = false, lf1 = false;
+        int c0 = 0, c1 = 0;
+        uint32_t v0 = 0, v1 = 0;
+        if (node >= 0) {
+          const LbvhNode nd = p.lbvh_nodes[node];
+          c0 = nd.child0; c1 = nd.child1;
+          const bool t0 = box_touches_pyramid(nd.lo0, nd.hi0, pl);
+          const bool t1 = box_touches_pyramid(nd.lo1, nd.hi1, pl);
+          in0 = t0 && c0 >= 0; in1 = t1 && c1 >= 0;
+          if (t0 && c0 < 0) { lf0 = capsule_touches_pyramid(p.lbvh_sA[~c0], p.lbvh_sB[~c0], pl); if (lf0) v0 = p.lbvh_perm[~c0]; }
+          if (t1 && c1 < 0) { lf1 = capsule_touches_pyramid(p.lbvh_sA[~c1], p.lbvh_sB[~c1], pl); if (lf1) v1 = p.lbvh_perm[~c1]; }
+        }
+        const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
+        const int n0 = __builtin_popcountll(m0);
+        if (in0) stack[top + (int)lanes_below(m0)] = c0;
+        if (in1) stack[top + n0 + (int)lanes_below(m1)] = c1;
+        top += n0 + __builtin_popcountll(m1);
+        append_candidates(p, w, lf0, v0, lane);
+        append_candidates(p, w, lf1, v1, lane);
+        __syncthreads();
+      }
+    } else {
+      for (int base = 0; base < p.n_seg; base += 64) {
+        const int s = base + lane;
+        bool touch = false;
+        if (s < p.n_seg) touch = capsule_touches_pyramid(p.capA[s], p.capB[s], pl);
+        append_candidates(p, w, touch, (uint32_t)s, lane);
+      }
     }
     if (w.count > 0) flush_chunk(p, w, w.count, lane);
   }
@@ -350,8 +399,11 @@ int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
   (void)mode;
   const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
   if (groups <= 0) return PB_OK;
-  if (count) hipLaunchKernelGGL(cull_kernel<true>, dim3(groups), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL(cull_kernel<false>, dim3(groups), dim3(64), 0, s, p);
+  const bool lbvh = p.lbvh_n >= 2;
+  if (count && lbvh) hipLaunchKernelGGL((cull_kernel<true, true>), dim3(groups), dim3(64), 0, s, p);
+  else if (count) hipLaunchKernelGGL((cull_kernel<true, false>), dim3(groups), dim3(64), 0, s, p);
+  else if (lbvh) hipLaunchKernelGGL((cull_kernel<false, true>), dim3(groups), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL((cull_kernel<false, false>), dim3(groups), dim3(64), 0, s, p);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }

@@ -334,3 +334,14 @@ def render_segments(control, tri_xyz9, m16, segs, root_lo, root_hi, x0, y0, w, h
                                   rgb.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.c_int(threads))
     assert r == 0, r
     return rgb, cnt.as_dict()
+
+
+def lbvh(segs):
+    """CPU twin of the GPU LBVH: sorted Morton keys, permutation, inner nodes (NODE_DTYPE)."""
+    segs = np.ascontiguousarray(segs)
+    n = len(segs)
+    keys = np.zeros(n, np.uint64); perm = np.zeros(n, np.uint32); nodes = np.zeros(max(n - 1, 0), NODE_DTYPE)
+    r = lib().orc_lbvh(segs.ctypes.data_as(C.c_void_p), C.c_int(n), keys.ctypes.data_as(C.c_void_p),
+                       perm.ctypes.data_as(C.c_void_p), nodes.ctypes.data_as(C.c_void_p))
+    assert r == (n if n >= 2 else 0), r
+    return keys, perm, nodes

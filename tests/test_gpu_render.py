@@ -53,7 +53,11 @@ def test_config1_tree_segments_full_frame(pb, cfg1, golden_dir):
         ctx.enable_counters(True)
         ctx.draw()
         cnt = ctx.counters()
+        ctx.enable_counters(False)
+        ctx.build_tree()
+        img_lbvh = ctx.draw(use_lbvh=True)
     maxerr, rmse = check_radiance(img, ref, "config 1")
+    check_radiance(img_lbvh, ref, "config 1 through the LBVH")
     print(f"config 1: max-abs {maxerr:.3e} rmse {rmse:.3e} counters {cnt}")
     assert cnt["rays"] == 262144 and cnt["rays_hit_scene"] == 262052
     assert cnt["valid_hits"] == 3144103          # the reference traversal's valid beam hits
