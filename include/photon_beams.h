@@ -111,6 +111,8 @@ typedef struct pb_stats {
                                 entered within the surface distance: the pairs on
                                 which the reference calls HitCylinder
                                 (BeamRadiance.h:428-439); counted by a full scan   */
+  uint64_t shortcut_wrong;   /* pairs that the fast gate shortcut accepted and the exact
+                                HitBoundingBox gate would have rejected (expected: 0)  */
   float ms_render;           /* device time of the last pb_render (HIP events)    */
   float ms_build;            /* device time of the last pb_build_lbvh             */
   float ms_prepare;          /* device time of the last segment upload/prepare    */
@@ -190,6 +192,13 @@ int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbv
  * tiles one GPU of several renders.  Output rows are packed: 8*n_strips rows. */
 int pb_render_strips_d(pb_ctx* ctx, int first_strip, int strip_stride, int n_strips, int mode,
                        int use_lbvh, float* d_rgb_out, void* stream);
+
+/* Arithmetic of the per-pair estimate.  0 (default): fused multiply-adds, hardware reciprocal and
+ * square root, entry/exit distances taken from the ray parameter; agrees with the reference to its own
+ * float rounding noise (well inside max-abs 2e-3*max(1,|ref|), RMSE 1e-4).  1: every operation of
+ * HitCylinder / Integral_721 in the reference's order with IEEE divide and sqrt (about 3x slower).
+ * The gate (HitBoundingBox + max_distance) is exact in both. */
+int pb_set_precise(pb_ctx* ctx, int on);
 
 /* PutPixelSDL (SDLauxiliary.h:149-161): RGB float -> 0x80RRGGBB, n pixels. */
 int pb_quantise_argb(const float* rgb, int n_pixels, uint32_t* argb_out);

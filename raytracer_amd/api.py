@@ -35,7 +35,7 @@ class Control(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rays_hit_scene", C.c_uint64), ("candidates", C.c_uint64),
-                ("cyl_hits", C.c_uint64), ("valid_hits", C.c_uint64), ("nodes_visited", C.c_uint64), ("gate_passes", C.c_uint64),
+                ("cyl_hits", C.c_uint64), ("valid_hits", C.c_uint64), ("nodes_visited", C.c_uint64), ("gate_passes", C.c_uint64), ("shortcut_wrong", C.c_uint64),
                 ("ms_render", C.c_float), ("ms_build", C.c_float), ("ms_prepare", C.c_float),
                 ("ms_emit", C.c_float)]
 
@@ -293,6 +293,10 @@ class Context:
         _check(self.L.pb_render_strips_d(self.h, C.c_int(first_strip), C.c_int(strip_stride), C.c_int(n_strips),
                                          C.c_int(mode), C.c_int(1 if use_lbvh else 0), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream)), "pb_render_strips_d")
+
+    def set_precise(self, on=True):
+        """Evaluate HitCylinder/Integral_721 in the reference's exact operation order (slower)."""
+        _check(self.L.pb_set_precise(self.h, C.c_int(1 if on else 0)), "pb_set_precise")
 
     # -- counters --------------------------------------------------------------
     def enable_counters(self, on=True):

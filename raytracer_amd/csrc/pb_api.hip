@@ -120,6 +120,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
     p.lbvh_nodes = ctx->lb_nodes; p.lbvh_sA = ctx->lb_sA; p.lbvh_sB = ctx->lb_sB; p.lbvh_perm = ctx->lb_perm;
     p.lbvh_n = ctx->lb_n;
   }
+  p.precise = ctx->precise ? 1 : 0;
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
 
@@ -423,6 +424,12 @@ int pb_quantise_argb(const float* rgb, int n_pixels, uint32_t* argb_out) {
   return PB_OK;
 }
 
+int pb_set_precise(pb_ctx* ctx, int on) {
+  if (!ctx) { pb_set_error("pb_set_precise: null context"); return PB_ERR_ARG; }
+  ctx->precise = on != 0;
+  return PB_OK;
+}
+
 int pb_enable_counters(pb_ctx* ctx, int on) {
   if (!ctx) { pb_set_error("pb_enable_counters: null context"); return PB_ERR_ARG; }
   ctx->count_on = on != 0;
@@ -445,6 +452,7 @@ int pb_counters(pb_ctx* ctx, pb_stats* out) {
   ctx->stats.candidates = h[PB_CNT_CAND]; ctx->stats.cyl_hits = h[PB_CNT_CYL];
   ctx->stats.valid_hits = h[PB_CNT_VALID]; ctx->stats.nodes_visited = h[PB_CNT_NODES];
   ctx->stats.gate_passes = h[PB_CNT_GATED];
+  ctx->stats.shortcut_wrong = h[PB_CNT_SHORTCUT_WRONG];
   *out = ctx->stats;
   return PB_OK;
 }

@@ -42,11 +42,13 @@ struct __attribute__((aligned(64))) SegFrame {
   float bdir[3];   // 26..28  normalize(end-start)
   float lo[3];     // 29..31  gate box, min_b of HitBoundingBox
   float hi[3];     // 32..34  max_b
-  uint32_t qflags; // 35      bit i: origin inside slab i (MIDDLE); bit 3: origin inside the box
+  uint32_t qflags; // 35      bit i: origin inside slab i (MIDDLE); bit 3: origin inside the box;
+                   //         bit 4: the gate box contains the segment's cylinder
   double W[3];     // 36..41  energy*(1/(4 PI))*(sigma_s/(PI r^2)) (721) or energy*(1/(4 PI)) (73het)
   float cand[3];   // 42..44  candidate planes of HitBoundingBox for the origin (0,0,0)
   float radius;    // 45
-  float pad[2];
+  float len;       // 46      |end-start|
+  float pad;
 };
 static_assert(sizeof(SegFrame) == 192, "SegFrame layout");
 
@@ -88,6 +90,7 @@ struct RenderParams {
   double* partials;         // [chunk_capacity][3][64]
   uint32_t* ctrl;           // [0] chunks produced, [1] chunks taken by eval waves
   int chunk_capacity;
+  int precise;              // 1: evaluate pairs in the reference's exact operation order
   // LBVH (lbvh_n < 2: scan all segments)
   const LbvhNode* lbvh_nodes;
   const float4* lbvh_sA;    // capsules in Morton order
@@ -101,7 +104,7 @@ constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 51
 constexpr int PB_EVAL_WAVES = 256 * 32;
 constexpr int PB_STACK_CAP = 2048;     // LBVH traversal stack entries per wave (plus 128 of slack) // one resident wave slot per SIMD lane group of the chip
 
-enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_N };
+enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_SHORTCUT_WRONG, PB_CNT_N };
 
 void pb_set_error(const std::string& msg);
 
@@ -157,6 +160,7 @@ struct pb_ctx {
   // counters
   unsigned long long* d_counters = nullptr;
   bool count_on = false;
+  bool precise = false;
   pb_stats stats;
 };
 

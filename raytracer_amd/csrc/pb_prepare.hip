@@ -101,6 +101,20 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
   f.bdir[0] = c_unit.x; f.bdir[1] = c_unit.y; f.bdir[2] = c_unit.z;
   for (int k = 0; k < 3; ++k) { f.lo[k] = s.cull_lo[k]; f.hi[k] = s.cull_hi[k]; }
   gate_setup(f.lo, f.hi, f.cand, f.qflags);
+  {
+    // does the gate box contain the flat-capped cylinder?  Its extent along axis k about an end point is
+    // r * sqrt(1 - dir_k^2); a few ulps of slack keep boxes that touch it (axis-parallel beams) in.
+    bool contains = true;
+    const float se[3][2] = {{start.x, end.x}, {start.y, end.y}, {start.z, end.z}};
+    const float dk[3] = {c_unit.x, c_unit.y, c_unit.z};
+    for (int k = 0; k < 3; ++k) {
+      const float e = s.radius * pb_sqrt(fmaxf(0.0f, 1.0f - dk[k] * dk[k]));
+      const float mn = fminf(se[k][0], se[k][1]) - e, mx = fmaxf(se[k][0], se[k][1]) + e;
+      const float tol = 4e-6f * (1.0f + fmaxf(fabsf(mn), fabsf(mx)));
+      contains = contains && (f.lo[k] <= mn + tol) && (f.hi[k] >= mx - tol);
+    }
+    if (contains && len > 0.0f) f.qflags |= 16u;
+  }
   // BeamRadiance.h:446-455 (721) / :389-397 (73het): energy * phase_f [* rad]
   double phase_f = 1 / (4 * PB_PI_REF);
   for (int k = 0; k < 3; ++k) {
@@ -112,7 +126,8 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
     f.W[k] = w;
   }
   f.radius = s.radius;
-  f.pad[0] = f.pad[1] = 0.0f;
+  f.len = len;
+  f.pad = 0.0f;
   frames[i] = f;
   capA[i] = make_float4(start.x, start.y, start.z, s.radius);
   capB[i] = make_float4(end.x, end.y, end.z, 0.0f);

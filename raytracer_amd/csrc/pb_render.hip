@@ -140,6 +140,88 @@ PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, doubl
   return 2;
 }
 
+// The same pair evaluation with the arithmetic the estimate is continuous in relaxed to what the
+// hardware does fastest; the radiance differs from the exact-order form above by the reference's own
+// float rounding noise (about 1e-5 relative per pixel), far inside the stated tolerance.
+//  * fused multiply-adds, v_rcp/v_sqrt instead of IEEE divide/sqrt;
+//  * entry/exit distances from the ray parameter: the rotation back to world space and its length
+//    (Intersections.h:443-450) return |l * th / S_inv| = th * |end - start| for a camera at the origin;
+//  * cos(theta) = -dot(beam_dir, l) is the y component of R_inv * l;
+//  * exp(x) - 1 by its series where |x| is small (the reference's float exp loses 4 digits there);
+//  * the gate: a segment whose gate box contains its cylinder (qflags bit 4) passes whenever the
+//    cylinder exit lies in front of the surface, since the box entry comes before it; otherwise, and for
+//    every other segment, the exact HitBoundingBox gate runs.
+PB_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+template <bool CHECK>
+PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double acc[3], unsigned long long& shortcut_wrong) {
+  const V3 l = r.l;
+  const float dpx = __builtin_fmaf(f.Rinv[6], l.z, __builtin_fmaf(f.Rinv[3], l.y, f.Rinv[0] * l.x));
+  const float dpz = __builtin_fmaf(f.Rinv[8], l.z, __builtin_fmaf(f.Rinv[5], l.y, f.Rinv[2] * l.x));
+  const float a = __builtin_fmaf(dpx, dpx, dpz * dpz);
+  const float b = __builtin_fmaf(f.ox2, dpx, f.oz2 * dpz);
+  const float b24ac = __builtin_fmaf(b, b, -(a * f.c4));
+  if (b24ac < 0) return 0;
+  const float sq = __builtin_amdgcn_sqrtf(b24ac);
+  const float inv2a = fast_rcp(a + a);
+  const float t0 = (-b - sq) * inv2a;     // a > 0: already ordered, t0 <= t1
+  const float t1 = (-b + sq) * inv2a;
+  const float dpy = __builtin_fmaf(f.Rinv[7], l.z, __builtin_fmaf(f.Rinv[4], l.y, f.Rinv[1] * l.x));
+  const float oy = f.Tinv[1];
+  const float y0 = __builtin_fmaf(t0, dpy, oy);
+  const float y1 = __builtin_fmaf(t1, dpy, oy);
+  float thf, ths = 0.0f;
+  bool have_second = false;
+  const float dt = t1 - t0;
+  if (y0 >= 0 && y0 <= 1) {
+    if (t0 <= 0) return 1;
+    thf = t0;
+    if (y1 >= 0 && y1 <= 1) { ths = t1; have_second = true; }
+    else {
+      const float q = fast_rcp(y0 - y1);
+      const float th2 = (y1 > 1) ? __builtin_fmaf(dt * (y1 - 1), q, t1) : __builtin_fmaf(dt * y0, q, t0);
+      if (th2 > 0) { ths = th2; have_second = true; }
+    }
+  } else if (y0 < 0) {
+    if (y1 < 0) return 1;
+    const float q = fast_rcp(y0 - y1);
+    thf = __builtin_fmaf(dt * y0, q, t0);
+    if (thf <= 0) return 1;
+    if (y1 <= 1) { ths = t1; have_second = true; }
+    else { const float th2 = __builtin_fmaf(dt * (y1 - 1), q, t1); if (th2 > 0) { ths = th2; have_second = true; } }
+  } else if (y0 > 1) {
+    if (y1 > 1) return 1;
+    const float q = fast_rcp(y0 - y1);
+    thf = __builtin_fmaf(dt * (y0 - 1), q, t0);
+    if (thf <= 0) return 1;
+    if (y1 >= 0) { ths = t1; have_second = true; }
+    else { const float th2 = __builtin_fmaf(dt * y0, q, t0); if (th2 > 0) { ths = th2; have_second = true; } }
+  } else return 1;
+  if (!((t0 > 0) && (t1 > t0))) return 1;
+  const float tc_minus = thf * f.len;
+  const float tc_plus = have_second ? ths * f.len : 0.0f;
+  const bool sure = (f.qflags & 16u) && have_second && (fmaxf(tc_minus, tc_plus) < r.maxd * 0.99999f);
+  if (!sure) {
+    if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
+  } else if (CHECK) {
+    if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) shortcut_wrong++;
+  }
+  const float fy = __builtin_fmaf(dpy, thf, oy);
+  const float sy = have_second ? __builtin_fmaf(dpy, ths, oy) : 0.0f;
+  const float tb_minus = f.tb0 + fminf(fy, sy) * f.len;
+  const float cm1 = fabsf(dpy) - 1.0f;
+  const float x = -extinction * (tc_minus - tc_plus) * cm1;
+  float num;
+  if (fabsf(x) < 0.02f) num = x * __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
+  else num = expf(x) - 1.0f;
+  const float den = __expf(extinction * (tc_minus + tb_minus)) * extinction * cm1;
+  const double integral = (double)(num * fast_rcp(den));
+  acc[0] = __builtin_fma(f.W[0], integral, acc[0]);
+  acc[1] = __builtin_fma(f.W[1], integral, acc[1]);
+  acc[2] = __builtin_fma(f.W[2], integral, acc[2]);
+  return 2;
+}
+
 // Conservative test: can the capsule (a, b, radius) touch the pyramid of the tile?
 // pl[k] are the four inward unit normals of the side planes (through the origin).
 PB_DI bool capsule_touches_pyramid(const float4 A, const float4 B, const V3 pl[4]) {
@@ -326,10 +408,10 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool PRECISE>
 __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
   const int lane = threadIdx.x;
-  unsigned long long c_cand = 0, c_cyl = 0, c_valid = 0;
+  unsigned long long c_cand = 0, c_cyl = 0, c_valid = 0, c_wrong = 0;
   const uint32_t produced = p.ctrl[0];
   const uint32_t n_chunks = produced < (uint32_t)p.chunk_capacity ? produced : (uint32_t)p.chunk_capacity;
   while (true) {
@@ -350,16 +432,17 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
     for (int k = 0; k < n; ++k) {
       const int sidx = (int)ch[4 + k];
       const SegFrame& f = p.frames[sidx];
-      const int res = eval_pair_721(f, r, p.extinction_c, acc);
+      const int res = PRECISE ? eval_pair_721(f, r, p.extinction_c, acc)
+                              : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, acc, c_wrong);
       if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
     }
     double* part = p.partials + (size_t)c * 3 * 64;
     part[0 * 64 + lane] = acc[0]; part[1 * 64 + lane] = acc[1]; part[2 * 64 + lane] = acc[2];
   }
   if (COUNT) {
-    unsigned long long v[3] = {c_cand, c_cyl, c_valid};
-    const int slot[3] = {PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID};
-    for (int k = 0; k < 3; ++k) {
+    unsigned long long v[4] = {c_cand, c_cyl, c_valid, c_wrong};
+    const int slot[4] = {PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_SHORTCUT_WRONG};
+    for (int k = 0; k < 4; ++k) {
       unsigned long long x = v[k];
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
       if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
@@ -414,8 +497,10 @@ int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream
   if (tiles <= 0) return PB_OK;
   int waves = p.chunk_capacity < PB_EVAL_WAVES ? p.chunk_capacity : PB_EVAL_WAVES;
   if (waves < 1) waves = 1;
-  if (count) hipLaunchKernelGGL(eval_kernel<true>, dim3(waves), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL(eval_kernel<false>, dim3(waves), dim3(64), 0, s, p);
+  if (count && p.precise) hipLaunchKernelGGL((eval_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
+  else if (count) hipLaunchKernelGGL((eval_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
+  else if (p.precise) hipLaunchKernelGGL((eval_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL((eval_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
   hipLaunchKernelGGL(reduce_kernel, dim3(tiles), dim3(64), 0, s, p);
   PB_HIP(hipGetLastError());
   return PB_OK;

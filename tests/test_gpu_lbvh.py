@@ -84,6 +84,7 @@ def test_lbvh_frame_equals_scan_frame(pb):
             ctx.draw(use_lbvh=True)                 # not built yet
         ctx.build_tree()
         ctx.enable_counters(True)
+        ctx.set_precise(True)
         a = ctx.draw(0, 128, 512, 256, use_lbvh=True); ca = ctx.counters()
         b = ctx.draw(0, 128, 512, 256, use_lbvh=False); cb = ctx.counters()
     assert ca["valid_hits"] == cb["valid_hits"] and ca["cyl_hits"] == cb["cyl_hits"]
