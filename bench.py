@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-lbvh", action="store_true", help="scan all segments per tile instead of the LBVH")
+    ap.add_argument("--cull", default="bins", choices=["bins", "lbvh", "scan"],
+                    help="how a tile finds its candidate segments (default: screen-space bins)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,13 +124,8 @@ def main():
             ctx.upload_segments_device(buf.data_ptr(), n_segs, root[:3], root[3:],
                                        stream=torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-    use_lbvh = False
-    if not args.no_lbvh:
-        try:
-            ctx.build_tree()
-            use_lbvh = True
-        except pb.PhotonBeamsError:
-            use_lbvh = False
+    cull = args.cull
+    ctx.build_tree()     # the LBVH is part of the photon pass whichever cull mode renders (ms_build)
 
     # ---- strips of this rank ----
     n_strips_total = H // 8
@@ -145,7 +141,7 @@ def main():
     def step(i=None):
         if i is not None:
             ev0[i].record()
-        ctx.draw_strips_device(mine.data_ptr(), rank, world, n_my, use_lbvh=use_lbvh, stream=stream)
+        ctx.draw_strips_device(mine.data_ptr(), rank, world, n_my, cull=cull, stream=stream)
         if i is not None:
             ev1[i].record()
         if world > 1:
@@ -185,7 +181,7 @@ def main():
         # algorithmic work per ray from the counters of one counted frame (not timed)
         ctx.enable_counters(True)
         full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-        ctx.draw_device(full.data_ptr(), 0, 0, W, H, use_lbvh=use_lbvh, stream=stream)
+        ctx.draw_device(full.data_ptr(), 0, 0, W, H, cull=cull, stream=stream)
         torch.cuda.synchronize()
         cnt = ctx.counters()
         ctx.enable_counters(False)
@@ -203,11 +199,11 @@ def main():
             "config": {"workload": f"{args.workload}: Cornell box {W}x{H}, {wk['photon_number']} photons, "
                                    f"BOUNCES {wk['bounces']}, homogeneous medium, SEED 42 (GPU photon pass: "
                                    f"{n_beams} beams, {n_segs} segments, own-box gate rule)",
-                       "rays_per_frame": rays, "segments": n_segs, "lbvh": use_lbvh,
+                       "rays_per_frame": rays, "segments": n_segs, "cull": cull,
                        "parallelism": f"row-strips x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": "render_tiles_721_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "frame = ray_setup + bin/cull + eval + finalize kernels", "kernel_ms": kernel_ms,
                          "flop_per_ray": w_ray, "n_cull_per_ray": n_cull, "n_valid_per_ray": n_valid,
                          "note": "FP32 vector-ALU bound (no MFMA, working set in L2); achieved = algorithmic "
                                  "flop per ray x rays per launch / measured launch time"},

@@ -183,7 +183,9 @@ int pb_download_lbvh(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes
  * rectangle [x0,x0+w) x [y0,y0+h): per pixel ClosestIntersection, then the
  * beam radiance estimate over the segment set.  Output is current/SSAA per
  * pixel as RGB, row-major h*w*3 (float: the dvec3 -> vec3 conversion at
- * PutPixelSDL, SDLauxiliary.h:149).  use_lbvh = 0 scans every segment.  */
+ * PutPixelSDL, SDLauxiliary.h:149).  use_lbvh selects how a tile finds its candidate segments:
+ * 0 scans every segment, 1 traverses the LBVH of pb_build_lbvh, 2 bins the segments by their
+ * projection (all camera rays share the origin) and sums in fixed point, order-independently. */
 int pb_render(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh, float* rgb_out);
 int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh,
                 float* d_rgb_out, void* stream);

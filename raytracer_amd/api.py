@@ -274,24 +274,31 @@ class Context:
         return keys, perm, nodes
 
     # -- frames ----------------------------------------------------------------
-    def draw(self, x0=0, y0=0, w=None, h=None, mode=MODE_721, use_lbvh=False):
-        """DrawStandard / DrawHet (skeleton.cpp:330-412) for a pixel rectangle: (h,w,3) float32 = current/SSAA."""
+    @staticmethod
+    def _cull(use_lbvh, cull):
+        if cull is None:
+            return 1 if use_lbvh else 0
+        return {"scan": 0, "lbvh": 1, "bins": 2}[cull]
+
+    def draw(self, x0=0, y0=0, w=None, h=None, mode=MODE_721, use_lbvh=False, cull=None):
+        """DrawStandard / DrawHet (skeleton.cpp:330-412) for a pixel rectangle: (h,w,3) float32 = current/SSAA.
+        cull: "scan" (every segment per tile), "lbvh" (after build_tree) or "bins" (screen-space bins)."""
         w = self.control.screen_width - x0 if w is None else w
         h = self.control.screen_height - y0 if h is None else h
         out = np.zeros((h, w, 3), np.float32)
         _check(self.L.pb_render(self.h, C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h), C.c_int(mode),
-                                C.c_int(1 if use_lbvh else 0), _fp(out)), "pb_render")
+                                C.c_int(self._cull(use_lbvh, cull)), _fp(out)), "pb_render")
         return out
 
-    def draw_device(self, d_out_ptr, x0, y0, w, h, mode=MODE_721, use_lbvh=False, stream=0):
+    def draw_device(self, d_out_ptr, x0, y0, w, h, mode=MODE_721, use_lbvh=False, stream=0, cull=None):
         _check(self.L.pb_render_d(self.h, C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h), C.c_int(mode),
-                                  C.c_int(1 if use_lbvh else 0), C.c_void_p(d_out_ptr), C.c_void_p(stream)),
+                                  C.c_int(self._cull(use_lbvh, cull)), C.c_void_p(d_out_ptr), C.c_void_p(stream)),
                "pb_render_d")
 
     def draw_strips_device(self, d_out_ptr, first_strip, strip_stride, n_strips, mode=MODE_721, use_lbvh=False,
-                           stream=0):
+                           stream=0, cull=None):
         _check(self.L.pb_render_strips_d(self.h, C.c_int(first_strip), C.c_int(strip_stride), C.c_int(n_strips),
-                                         C.c_int(mode), C.c_int(1 if use_lbvh else 0), C.c_void_p(d_out_ptr),
+                                         C.c_int(mode), C.c_int(self._cull(use_lbvh, cull)), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream)), "pb_render_strips_d")
 
     def set_precise(self, on=True):

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "pb_internal.h"
+#include "pb_scan.h"
 
 static thread_local std::string g_last_error;
 void pb_set_error(const std::string& msg) { g_last_error = msg; }
@@ -93,12 +94,101 @@ int ensure_workspace(pb_ctx* ctx, int groups, int chunks) {
   return PB_OK;
 }
 
+int ensure_bin_workspace(pb_ctx* ctx, int tiles, int bin_cap, int item_cap, size_t accum_px) {
+  if (tiles > ctx->ws_tiles) {
+    if (ctx->d_tile_u32) PB_HIP(hipFree(ctx->d_tile_u32));
+    if (ctx->d_scan_tmp) PB_HIP(hipFree(ctx->d_scan_tmp));
+    ctx->d_tile_u32 = nullptr; ctx->d_scan_tmp = nullptr; ctx->ws_tiles = 0;
+    PB_HIP(hipMalloc(&ctx->d_tile_u32, sizeof(uint32_t) * (2 + 3 * (size_t)PB_BIN_SUBS) * (size_t)tiles));   // macro tiles <= tiles
+    PB_HIP(hipMalloc(&ctx->d_scan_tmp, sizeof(uint32_t) * pb_scan_tmp_words(tiles * PB_BIN_SUBS)));
+    ctx->ws_tiles = tiles;
+  }
+  if (bin_cap > ctx->ws_bin_cap) {
+    if (ctx->d_bin_list) PB_HIP(hipFree(ctx->d_bin_list));
+    ctx->d_bin_list = nullptr; ctx->ws_bin_cap = 0;
+    PB_HIP(hipMalloc(&ctx->d_bin_list, sizeof(uint32_t) * (size_t)bin_cap));
+    ctx->ws_bin_cap = bin_cap;
+  }
+  if (item_cap > ctx->ws_item_cap) {
+    if (ctx->d_items) PB_HIP(hipFree(ctx->d_items));
+    ctx->d_items = nullptr; ctx->ws_item_cap = 0;
+    PB_HIP(hipMalloc(&ctx->d_items, sizeof(uint32_t) * 4 * (size_t)item_cap));
+    ctx->ws_item_cap = item_cap;
+  }
+  if (accum_px > ctx->ws_accum_px) {
+    if (ctx->d_accum) PB_HIP(hipFree(ctx->d_accum));
+    ctx->d_accum = nullptr; ctx->ws_accum_px = 0;
+    PB_HIP(hipMalloc(&ctx->d_accum, sizeof(unsigned long long) * 3 * accum_px));
+    ctx->ws_accum_px = accum_px;
+  }
+  return PB_OK;
+}
+
+// Frame through screen-space bins (cull mode 2); p is complete except for the workspace pointers.
+int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long long key[6], hipStream_t s) {
+  const int tiles = p.tiles_x * p.tiles_y;
+  const int groups = tiles * p.ssaa * p.ssaa;
+  const size_t px = (size_t)p.out_w * p.out_h;
+  bool verified = std::memcmp(key, ctx->ws_key, sizeof(unsigned long long) * 6) == 0;
+  int want_bins = ctx->ws_bin_cap, want_items = ctx->ws_item_cap;
+  if (!verified) {
+    if (want_bins < tiles * 64 + 1024) want_bins = tiles * 64 + 1024;
+    if (want_items < groups * 2 + 1024) want_items = groups * 2 + 1024;
+  }
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    int rc = ensure_workspace(ctx, groups, 0);
+    if (rc != PB_OK) return rc;
+    rc = ensure_bin_workspace(ctx, tiles, want_bins, want_items, px);
+    if (rc != PB_OK) return rc;
+    p.rays = ctx->d_rays; p.group_last = ctx->d_group_last; p.ctrl = ctx->d_ctrl;
+    const int mtiles = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
+    {
+      const size_t T = (size_t)ctx->ws_tiles;
+      p.tile_count = ctx->d_tile_u32; p.item_off = ctx->d_tile_u32 + T;
+      p.sub_count = ctx->d_tile_u32 + 2 * T; p.sub_fill = p.sub_count + T * PB_BIN_SUBS; p.sub_off = p.sub_fill + T * PB_BIN_SUBS;
+    }
+    p.bin_list = ctx->d_bin_list; p.items = ctx->d_items; p.accum = ctx->d_accum;
+    p.bin_capacity = ctx->ws_bin_cap; p.item_capacity = ctx->ws_item_cap;
+    PB_HIP(hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * 4, s));
+    PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ctx->ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
+    PB_HIP(hipMemsetAsync(ctx->d_accum, 0, sizeof(unsigned long long) * 3 * px, s));
+    PB_HIP(hipEventRecord(ctx->ev[0], s));
+    rc = pb_launch_ray_setup(p, ctx->count_on, s);
+    if (rc != PB_OK) return rc;
+    rc = pb_launch_bin_count(p, s);
+    if (rc != PB_OK) return rc;
+    rc = pb_exclusive_scan_u32(p.sub_count, p.sub_off, mtiles * PB_BIN_SUBS, ctx->d_ctrl + 2, ctx->d_scan_tmp, s);
+    if (rc != PB_OK) return rc;
+    rc = pb_exclusive_scan_u32(p.item_off, p.item_off, tiles, ctx->d_ctrl + 0, ctx->d_scan_tmp, s);
+    if (rc != PB_OK) return rc;
+    if (verified) break;
+    PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+    PB_HIP(hipStreamSynchronize(s));
+    const uint32_t need_items = ctx->h_ctrl[0], need_bins = ctx->h_ctrl[2];
+    if (need_items <= (uint32_t)ctx->ws_item_cap && need_bins <= (uint32_t)ctx->ws_bin_cap) {
+      std::memcpy(ctx->ws_key, key, sizeof(unsigned long long) * 6);
+      verified = true;
+      break;
+    }
+    if (need_items > (uint32_t)ctx->ws_item_cap) want_items = (int)(need_items + need_items / 4 + 64);
+    if (need_bins > (uint32_t)ctx->ws_bin_cap) want_bins = (int)(need_bins + need_bins / 4 + 64);
+    if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
+  }
+  if (!verified) { pb_set_error("pb_render: bin workspace could not be sized"); return PB_ERR_CAPACITY; }
+  int rc = pb_launch_bin_fill_eval(p, mode, ctx->count_on, s);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipEventRecord(ctx->ev[1], s));
+  ctx->ev_valid[0] = true;
+  return PB_OK;
+}
+
 int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_stride, int mode, int use_lbvh,
                   float* d_out, hipStream_t s) {
   if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
   if (!ctx->have_segments) { pb_set_error("pb_render: no segment set (pb_upload_segments / pb_emit_beams)"); return PB_ERR_STATE; }
   if (mode != PB_MODE_721 && mode != PB_MODE_73HET) { pb_set_error("pb_render: mode must be PB_MODE_721 or PB_MODE_73HET"); return PB_ERR_ARG; }
-  if (use_lbvh && (ctx->lb_n < 0 || ctx->lb_version != ctx->segs_version)) {
+  if (use_lbvh < 0 || use_lbvh > 2) { pb_set_error("pb_render: cull mode must be 0 (scan), 1 (LBVH) or 2 (screen bins)"); return PB_ERR_ARG; }
+  if (use_lbvh == 1 && (ctx->lb_n < 0 || ctx->lb_version != ctx->segs_version)) {
     pb_set_error("pb_render: pb_build_lbvh has not been called for this segment set"); return PB_ERR_STATE;
   }
   if (ctx->frame_mode != mode) {
@@ -116,7 +206,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.x0 = x0; p.y0 = y0; p.out_w = out_w; p.out_h = out_h; p.strip_stride = strip_stride;
   p.tiles_x = (out_w + 7) / 8; p.tiles_y = (out_h + 7) / 8;
   p.out = d_out;
-  if (use_lbvh && ctx->lb_n >= 2) {
+  if (use_lbvh == 1 && ctx->lb_n >= 2) {
     p.lbvh_nodes = ctx->lb_nodes; p.lbvh_sA = ctx->lb_sA; p.lbvh_sB = ctx->lb_sB; p.lbvh_perm = ctx->lb_perm;
     p.lbvh_n = ctx->lb_n;
   }
@@ -132,8 +222,9 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
                                      ((unsigned long long)(uint32_t)x0 << 32) | (uint32_t)y0,
                                      ((unsigned long long)(uint32_t)out_w << 32) | (uint32_t)out_h,
                                      (unsigned long long)strip_stride,
-                                     (unsigned long long)(use_lbvh ? 1 : 0),
+                                     (unsigned long long)use_lbvh,
                                      (unsigned long long)mode};
+  if (use_lbvh == 2) return render_binned(ctx, p, mode, key, s);
   bool verified = std::memcmp(key, ctx->ws_key, sizeof(key)) == 0;
   int want_chunks = ctx->ws_chunks;
   if (!verified && want_chunks < groups * 2 + 1024) want_chunks = groups * 2 + 1024;
@@ -224,7 +315,8 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
                   ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_rays, ctx->d_group_last,
-                  ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
+                  ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->d_tile_u32, ctx->d_bin_list, ctx->d_items, ctx->d_accum,
+                  ctx->d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
                   ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);

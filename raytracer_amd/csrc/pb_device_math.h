@@ -10,6 +10,18 @@
 #include <hip/hip_runtime.h>
 
 #define PB_DI __device__ __forceinline__
+// Read-only data that no kernel of the same launch writes can be addressed through the constant address
+// space: a load whose address is wave-uniform then goes through the scalar unit (s_load) into SGPRs
+// instead of sixty-four identical vector loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PB_CONST_AS __attribute__((address_space(4)))
+#else
+#define PB_CONST_AS   /* host pass: kernels are only parsed */
+#endif
+template <class T>
+__device__ __forceinline__ const PB_CONST_AS T* pb_uniform(const T* p) {
+  return (const PB_CONST_AS T*)(p);
+}
 #define PB_HDI __host__ __device__ __forceinline__
 
 struct V3 { float x, y, z; };

@@ -91,6 +91,16 @@ struct RenderParams {
   uint32_t* ctrl;           // [0] chunks produced, [1] chunks taken by eval waves
   int chunk_capacity;
   int precise;              // 1: evaluate pairs in the reference's exact operation order
+  // screen-space bins (pb_bins.hip)
+  uint32_t* tile_count;     // [tiles] length of the tile's macro list
+  uint32_t* sub_count;      // [macro tiles][PB_BIN_SUBS] candidates per macro tile and sub-counter
+  uint32_t* sub_fill;       // [macro tiles][PB_BIN_SUBS] fill cursors of the second binning pass
+  uint32_t* sub_off;        // [macro tiles][PB_BIN_SUBS] start of each sub-list in bin_list (a macro tile's are adjacent)
+  uint32_t* bin_list;       // [bin_capacity] segment indices, grouped by tile
+  uint32_t* items;          // [items][4]: group, start, n, 0
+  uint32_t* item_off;       // [tiles] first item of the tile
+  unsigned long long* accum;// [out_h*out_w][3] fixed-point radiance sums
+  int bin_capacity, item_capacity;
   // LBVH (lbvh_n < 2: scan all segments)
   const LbvhNode* lbvh_nodes;
   const float4* lbvh_sA;    // capsules in Morton order
@@ -102,7 +112,15 @@ struct RenderParams {
 constexpr int PB_CHUNK = 124;          // candidates per chunk
 constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 512 B
 constexpr int PB_EVAL_WAVES = 256 * 32;
-constexpr int PB_STACK_CAP = 2048;     // LBVH traversal stack entries per wave (plus 128 of slack) // one resident wave slot per SIMD lane group of the chip
+constexpr int PB_MACRO = 8;             // a macro tile is PB_MACRO x PB_MACRO tiles (64 x 64 pixels)
+constexpr int PB_SLICE = 512;           // candidates of a macro list handed to one evaluation item
+constexpr int PB_BIN_SUBS = 32;         // sub-counters per tile in the binning passes (power of two)
+constexpr int PB_STACK_CAP = 2048;
+// Fixed-point radiance accumulation of the binned path: contributions are rounded to multiples of 2^-40
+// (9e-13) by adding PB_FIX_MAGIC = 1.5 * 2^12 in double, and summed as 64-bit integers, so the sum does
+// not depend on the order in which candidates are met.  Valid for |contribution| < 2048.
+#define PB_FIX_MAGIC 6144.0
+#define PB_FIX_SCALE 9.094947017729282e-13   /* 2^-40 */     // LBVH traversal stack entries per wave (plus 128 of slack) // one resident wave slot per SIMD lane group of the chip
 
 enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_SHORTCUT_WRONG, PB_CNT_N };
 
@@ -155,6 +173,13 @@ struct pb_ctx {
   uint32_t* d_ctrl = nullptr;
   uint32_t* h_ctrl = nullptr;          // pinned
   int ws_groups = 0, ws_chunks = 0;
+  uint32_t* d_tile_u32 = nullptr;      // tile_count | item_off (ws_tiles each) | sub_count | sub_fill | sub_off (macro)
+  uint32_t* d_bin_list = nullptr;
+  uint32_t* d_items = nullptr;
+  unsigned long long* d_accum = nullptr;
+  uint32_t* d_scan_tmp = nullptr;
+  int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_scan_words = 0;
+  size_t ws_accum_px = 0;
   unsigned long long segs_version = 0; // bumped whenever the segment set or scene changes
   unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // frame geometry the chunk capacity was verified for
   // counters
@@ -186,5 +211,8 @@ int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float 
                                float4* d_capA, float4* d_capB, hipStream_t s);
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);
+int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);
+int pb_launch_bin_count(const RenderParams& p, hipStream_t s);
+int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s);
 
 #endif

@@ -68,7 +68,7 @@ PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
 // the two gates, Integral_721 (BeamRadiance.h:86-110) and the accumulation of
 // BeamRadianceStandard (BeamRadiance.h:441-455).  Returns 0 = no cylinder hit,
 // 1 = discriminant >= 0 but no contribution, 2 = contributed.
-PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, double acc[3]) {
+PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, double& integral_out) {
   const V3 l = r.l;
   const float dpx = f.Rinv[0] * l.x + f.Rinv[3] * l.y + f.Rinv[6] * l.z;
   const float dpz = f.Rinv[2] * l.x + f.Rinv[5] * l.y + f.Rinv[8] * l.z;
@@ -133,10 +133,7 @@ PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, doubl
   const float cm1 = fabsf(cos_theta) - 1;
   const float num = expf(-extinction * (tc_minus - tc_plus) * cm1) - 1;
   const float den = expf(extinction * (tc_minus + tb_minus)) * extinction * cm1;
-  const double integral = (double)num / (double)den;
-  acc[0] = acc[0] + f.W[0] * integral;
-  acc[1] = acc[1] + f.W[1] * integral;
-  acc[2] = acc[2] + f.W[2] * integral;
+  integral_out = (double)num / (double)den;
   return 2;
 }
 
@@ -154,7 +151,7 @@ PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, doubl
 PB_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 template <bool CHECK>
-PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double acc[3], unsigned long long& shortcut_wrong) {
+PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong) {
   const V3 l = r.l;
   const float dpx = __builtin_fmaf(f.Rinv[6], l.z, __builtin_fmaf(f.Rinv[3], l.y, f.Rinv[0] * l.x));
   const float dpz = __builtin_fmaf(f.Rinv[8], l.z, __builtin_fmaf(f.Rinv[5], l.y, f.Rinv[2] * l.x));
@@ -215,10 +212,7 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
   if (fabsf(x) < 0.02f) num = x * __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
   else num = expf(x) - 1.0f;
   const float den = __expf(extinction * (tc_minus + tb_minus)) * extinction * cm1;
-  const double integral = (double)(num * fast_rcp(den));
-  acc[0] = __builtin_fma(f.W[0], integral, acc[0]);
-  acc[1] = __builtin_fma(f.W[1], integral, acc[1]);
-  acc[2] = __builtin_fma(f.W[2], integral, acc[2]);
+  integral_out = (double)(num * fast_rcp(den));
   return 2;
 }
 
@@ -303,6 +297,21 @@ PB_DI bool box_touches_pyramid(const float lo[3], const float hi[3], const V3 pl
   return ok;
 }
 
+// Inward unit normals of the four side planes (through the origin) of the pyramid spanned by all
+// sub-rays of tile (tx, tk), widened by half a sub-pixel.
+PB_DI void tile_planes(const RenderParams& p, int tx, int tk, V3 pl[4]) {
+  const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
+  const float xl = (float)((p.x0 + 8 * tx) * p.ssaa) - half_w - 0.5f;
+  const float xr = (float)((p.x0 + 8 * tx + 7) * p.ssaa + p.ssaa - 1) - half_w + 0.5f;
+  const int ty0 = p.y0 + 8 * tk * p.strip_stride;
+  const float yt = (float)(ty0 * p.ssaa) - half_h - 0.5f;
+  const float yb = (float)((ty0 + 7) * p.ssaa + p.ssaa - 1) - half_h + 0.5f;
+  pl[0] = normalize3(v3(p.focal, 0.0f, -xl));    // x/z >= xl/focal
+  pl[1] = normalize3(v3(-p.focal, 0.0f, xr));    // x/z <= xr/focal
+  pl[2] = normalize3(v3(0.0f, p.focal, -yt));
+  pl[3] = normalize3(v3(0.0f, -p.focal, yb));
+}
+
 template <bool COUNT, bool LBVH>
 __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   __shared__ uint32_t buf[PB_CHUNK + 64];
@@ -333,18 +342,8 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   w.buf = buf; w.count = 0; w.prev = -1; w.group = group;
   unsigned long long c_gated = 0;
   if (__ballot(r.active) != 0ull) {
-    // side planes of the tile pyramid in sub-ray coordinates (wave-uniform)
-    const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
-    const float xl = (float)((p.x0 + 8 * tx) * p.ssaa) - half_w - 0.5f;
-    const float xr = (float)((p.x0 + 8 * tx + 7) * p.ssaa + p.ssaa - 1) - half_w + 0.5f;
-    const int ty0 = p.y0 + 8 * tk * p.strip_stride;
-    const float yt = (float)(ty0 * p.ssaa) - half_h - 0.5f;
-    const float yb = (float)((ty0 + 7) * p.ssaa + p.ssaa - 1) - half_h + 0.5f;
     V3 pl[4];
-    pl[0] = normalize3(v3(p.focal, 0.0f, -xl));    // x/z >= xl/focal
-    pl[1] = normalize3(v3(-p.focal, 0.0f, xr));    // x/z <= xr/focal
-    pl[2] = normalize3(v3(0.0f, p.focal, -yt));
-    pl[3] = normalize3(v3(0.0f, -p.focal, yb));
+    tile_planes(p, tx, tk, pl);   // wave-uniform
     if (COUNT) {
       // the pairs on which the reference calls HitCylinder: both gates pass, cylinder or not
       for (int sidx = 0; sidx < p.n_seg; ++sidx) {
@@ -419,7 +418,7 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
     if (lane == 0) c = atomicAdd(&p.ctrl[1], 1u);
     c = __builtin_amdgcn_readfirstlane(c);
     if (c >= n_chunks) break;              // every wave reaches this: the counter only grows
-    const uint32_t* ch = p.chunks + (size_t)c * PB_CHUNK_WORDS;
+    const PB_CONST_AS uint32_t* ch = pb_uniform(p.chunks + (size_t)c * PB_CHUNK_WORDS);
     const int group = (int)ch[0];
     const int n = (int)ch[1];
     const float* rr = p.rays + (size_t)group * 8 * 64;
@@ -431,9 +430,16 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
     double acc[3] = {0.0, 0.0, 0.0};
     for (int k = 0; k < n; ++k) {
       const int sidx = (int)ch[4 + k];
-      const SegFrame& f = p.frames[sidx];
-      const int res = PRECISE ? eval_pair_721(f, r, p.extinction_c, acc)
-                              : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, acc, c_wrong);
+      const SegFrame f = pb_uniform(p.frames)[sidx];
+      double integral = 0.0;
+      const int res = PRECISE ? eval_pair_721(f, r, p.extinction_c, integral)
+                              : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, integral, c_wrong);
+      if (res == 2) {
+        // BeamRadiance.h:455: current += energy * phase_f * rad * _int, product and sum rounded separately
+        acc[0] = acc[0] + f.W[0] * integral;
+        acc[1] = acc[1] + f.W[1] * integral;
+        acc[2] = acc[2] + f.W[2] * integral;
+      }
       if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
     }
     double* part = p.partials + (size_t)c * 3 * 64;
@@ -476,6 +482,299 @@ __global__ __launch_bounds__(64) void reduce_kernel(const RenderParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Binned frame (cull mode 2).  All camera rays leave (0,0,0), so which tiles a segment can touch
+// follows from its projection.
+//  ray_setup_kernel  one wave per ray group: the 64 rays (ClosestIntersection, root gate), stored.
+//  bin_kernel        one lane per segment: appends the segment to the list of every macro tile
+//                    (PB_MACRO x PB_MACRO tiles) whose pyramid its axis can touch; a counting pass, a
+//                    prefix sum, a filling pass.
+//  eval_bins_kernel  a fixed grid of waves pulls items (ray group, slice of its macro tile's list): lanes
+//                    first test 64 candidates at a time against the 8x8 tile's own pyramid and compact the
+//                    survivors in LDS, then every lane evaluates its ray against each survivor.
+//  finalize_kernel   fixed-point sums -> current / SSAA.
+// The lists are filled with atomics, hence in no fixed order; the radiance is therefore summed in fixed
+// point (PB_FIX_MAGIC), which makes the sum independent of that order and the image reproducible bit
+// for bit.
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
+  const int lane = threadIdx.x;
+  const int group = blockIdx.x;
+  const int nsub = p.ssaa * p.ssaa;
+  const int tile = group / nsub, sub = group % nsub;
+  const int si = sub / p.ssaa, sj = sub % p.ssaa;
+  const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
+  const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
+  const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + (lane >> 3);
+  const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
+  Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
+  r.active = r.active && in_image;
+  const bool hit_scene = r.active;
+  r.active = r.active && box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd);
+  if (!r.active) r.maxd = -1.0f;
+  float* rr = p.rays + (size_t)group * 8 * 64;
+  rr[0 * 64 + lane] = r.l.x; rr[1 * 64 + lane] = r.l.y; rr[2 * 64 + lane] = r.l.z;
+  rr[3 * 64 + lane] = r.dn.x; rr[4 * 64 + lane] = r.dn.y; rr[5 * 64 + lane] = r.dn.z;
+  rr[6 * 64 + lane] = r.maxd; rr[7 * 64 + lane] = 0.0f;
+  const bool any = __ballot(r.active) != 0ull;
+  if (lane == 0) p.group_last[group] = any ? 0 : -1;
+  if (COUNT) {
+    unsigned long long c_gated = 0;
+    if (any)
+      for (int sidx = 0; sidx < p.n_seg; ++sidx) {
+        const SegFrame f = pb_uniform(p.frames)[sidx];
+        c_gated += box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd) ? 1 : 0;
+      }
+    unsigned long long v[3] = {in_image ? 1ull : 0ull, hit_scene ? 1ull : 0ull, c_gated};
+    const int slot[3] = {PB_CNT_RAYS, PB_CNT_RAYS_HIT, PB_CNT_GATED};
+    for (int k = 0; k < 3; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
+    }
+  }
+}
+
+// Inward unit normals of the side planes of the pyramid spanned by the sub-rays of the pixel rectangle
+// [px0, px1] x [py0, py1] (pixel coordinates of this launch's frame), widened by half a sub-pixel.
+PB_DI void pixel_rect_planes(const RenderParams& p, int px0, int px1, int py0, int py1, V3 pl[4]) {
+  const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
+  const float xl = (float)(px0 * p.ssaa) - half_w - 0.5f;
+  const float xr = (float)(px1 * p.ssaa + p.ssaa - 1) - half_w + 0.5f;
+  const float yt = (float)(py0 * p.ssaa) - half_h - 0.5f;
+  const float yb = (float)(py1 * p.ssaa + p.ssaa - 1) - half_h + 0.5f;
+  pl[0] = normalize3(v3(p.focal, 0.0f, -xl));
+  pl[1] = normalize3(v3(-p.focal, 0.0f, xr));
+  pl[2] = normalize3(v3(0.0f, p.focal, -yt));
+  pl[3] = normalize3(v3(0.0f, -p.focal, yb));
+}
+
+// Macro tile (mx, my): PB_MACRO x PB_MACRO tiles.  With interleaved strips its tile rows are
+// strip_stride apart; the pyramid then also spans the rows in between (conservative).
+PB_DI void macro_planes(const RenderParams& p, int mx, int my, V3 pl[4]) {
+  const int tx0 = mx * PB_MACRO, tk0 = my * PB_MACRO;
+  int tx1 = tx0 + PB_MACRO - 1, tk1 = tk0 + PB_MACRO - 1;
+  if (tx1 > p.tiles_x - 1) tx1 = p.tiles_x - 1;
+  if (tk1 > p.tiles_y - 1) tk1 = p.tiles_y - 1;
+  pixel_rect_planes(p, p.x0 + 8 * tx0, p.x0 + 8 * tx1 + 7, p.y0 + 8 * tk0 * p.strip_stride,
+                    p.y0 + 8 * tk1 * p.strip_stride + 7, pl);
+}
+
+// Is some point of the axis a-b within `slack` of all four half-spaces at once?  Clips the parameter
+// interval [0,1] by each plane; tighter than testing the end points plane by plane.
+PB_DI bool axis_touches_pyramid(const float4 A, const float4 B, const V3 pl[4]) {
+  const float slack = A.w * 1.001f + 1e-5f;
+  float t0 = -1e-5f, t1 = 1.0f + 1e-5f;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float fa = pl[k].x * A.x + pl[k].y * A.y + pl[k].z * A.z + slack;
+    const float fb = pl[k].x * B.x + pl[k].y * B.y + pl[k].z * B.z + slack;
+    ok = ok && !(fa < 0.0f && fb < 0.0f);
+    const float t = fa * fast_rcp(fa - fb);          // only used when fa and fb differ in sign
+    if (fa < 0.0f && fb >= 0.0f) t0 = fmaxf(t0, t - 1e-5f);
+    if (fb < 0.0f && fa >= 0.0f) t1 = fminf(t1, t + 1e-5f);
+  }
+  return ok && (t0 <= t1);
+}
+
+struct TileRect { int x0, x1, y0, y1; };   // inclusive; empty if x1 < x0
+
+// Macro tiles whose pyramid can come within `pad` of the segment (a, b): bounds of the two projected
+// end spheres.  Segments reaching behind z = 0.05 are tested against every macro tile.
+PB_DI TileRect macro_rect(const RenderParams& p, V3 a, V3 b, float pad, int mtx, int mty) {
+  TileRect r;
+  r.x0 = 0; r.x1 = mtx - 1; r.y0 = 0; r.y1 = mty - 1;
+  if (fminf(a.z, b.z) - pad <= 0.05f) return r;
+  const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
+  float lo[2] = {3.4e38f, 3.4e38f}, hi[2] = {-3.4e38f, -3.4e38f};
+  const V3 pts[2] = {a, b};
+  for (int k = 0; k < 2; ++k) {
+    const float c[2] = {pts[k].x, pts[k].y};
+    const float zn = 1.0f / (pts[k].z - pad), zf = 1.0f / (pts[k].z + pad);
+    for (int ax = 0; ax < 2; ++ax) {
+      const float m = c[ax] - pad, q = c[ax] + pad;
+      lo[ax] = fminf(lo[ax], fminf(m * zn, m * zf));
+      hi[ax] = fmaxf(hi[ax], fmaxf(q * zn, q * zf));
+    }
+  }
+  // sub-ray coordinate s = u * focal + half; pixel = s / ssaa; one pixel of margin
+  const float inv = 1.0f / (float)p.ssaa;
+  const float sx = 1.0f / (float)(8 * PB_MACRO), sy = 1.0f / (float)(8 * PB_MACRO * p.strip_stride);
+  const float fx0 = ((lo[0] * p.focal + half_w) * inv - 1.0f - (float)p.x0) * sx;
+  const float fx1 = ((hi[0] * p.focal + half_w) * inv + 1.0f - (float)p.x0) * sx;
+  const float fy0 = ((lo[1] * p.focal + half_h) * inv - 1.0f - (float)p.y0) * sy;
+  const float fy1 = ((hi[1] * p.focal + half_h) * inv + 1.0f - (float)p.y0) * sy;
+  if (fx1 < 0.0f || fy1 < 0.0f) { r.x1 = -1; return r; }
+  r.x0 = (int)fmaxf(floorf(fx0), 0.0f);
+  r.x1 = (int)fminf(floorf(fx1), (float)(mtx - 1));
+  r.y0 = (int)fmaxf(floorf(fy0), 0.0f);
+  r.y1 = (int)fminf(floorf(fy1), (float)(mty - 1));
+  return r;
+}
+
+// One lane per segment: append the segment to every macro tile its axis can touch.
+template <bool FILL>
+__global__ __launch_bounds__(256) void bin_kernel(const RenderParams p) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.n_seg) return;
+  const float4 A4 = p.capA[s], B4 = p.capB[s];
+  const float pad = A4.w * 1.001f + 1e-5f;
+  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO, mty = (p.tiles_y + PB_MACRO - 1) / PB_MACRO;
+  const TileRect rc = macro_rect(p, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), pad, mtx, mty);
+  for (int my = rc.y0; my <= rc.y1; ++my)
+    for (int mx = rc.x0; mx <= rc.x1; ++mx) {
+      V3 pl[4];
+      macro_planes(p, mx, my, pl);
+      if (!axis_touches_pyramid(A4, B4, pl)) continue;
+      // PB_BIN_SUBS counters per macro tile, picked by the segment index: a tile over the light source
+      // receives every beam, and that many atomics on one address would serialise
+      const size_t slot = (size_t)(my * mtx + mx) * PB_BIN_SUBS + ((uint32_t)s & (PB_BIN_SUBS - 1));
+      if (FILL) {
+        const uint32_t pos = atomicAdd(&p.sub_fill[slot], 1u);
+        const uint32_t at = p.sub_off[slot] + pos;
+        if (at < (uint32_t)p.bin_capacity) p.bin_list[at] = (uint32_t)s;
+      } else atomicAdd(&p.sub_count[slot], 1u);
+    }
+}
+
+// Items of a tile: the list of its macro tile cut into slices of PB_SLICE, for each sub-sample group.
+// A tile none of whose rays is active gets none.
+PB_DI uint32_t macro_count(const RenderParams& p, int m) {
+  uint32_t cnt = 0;
+  for (int k = 0; k < PB_BIN_SUBS; ++k) cnt += p.sub_count[(size_t)m * PB_BIN_SUBS + k];
+  return cnt;
+}
+
+__global__ __launch_bounds__(256) void tile_items_kernel(const RenderParams p, int n_tiles) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  const int nsub = p.ssaa * p.ssaa;
+  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
+  const int m = ((t / p.tiles_x) / PB_MACRO) * mtx + (t % p.tiles_x) / PB_MACRO;
+  const uint32_t cnt = macro_count(p, m);
+  p.tile_count[t] = cnt;
+  uint32_t n_items = 0;
+  for (int q = 0; q < nsub; ++q)
+    if (p.group_last[t * nsub + q] >= 0) n_items += (cnt + PB_SLICE - 1) / PB_SLICE;
+  p.item_off[t] = n_items;
+}
+
+__global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, int n_tiles) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  const uint32_t cnt = p.tile_count[t];
+  const uint32_t slices = (cnt + PB_SLICE - 1) / PB_SLICE;
+  const int nsub = p.ssaa * p.ssaa;
+  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
+  const int m = ((t / p.tiles_x) / PB_MACRO) * mtx + (t % p.tiles_x) / PB_MACRO;
+  const uint32_t list0 = p.sub_off[(size_t)m * PB_BIN_SUBS];
+  uint32_t it = p.item_off[t];
+  for (int q = 0; q < nsub; ++q) {
+    if (p.group_last[t * nsub + q] < 0) continue;
+    for (uint32_t c = 0; c < slices; ++c, ++it) {
+      if (it >= (uint32_t)p.item_capacity) return;
+      uint32_t* dst = p.items + (size_t)it * 4;
+      const uint32_t n = (cnt - c * PB_SLICE < (uint32_t)PB_SLICE) ? cnt - c * PB_SLICE : (uint32_t)PB_SLICE;
+      dst[0] = (uint32_t)(t * nsub + q); dst[1] = list0 + c * PB_SLICE; dst[2] = n; dst[3] = 0u;
+    }
+  }
+}
+
+template <bool COUNT, bool PRECISE>
+__global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  const int lane = threadIdx.x;
+  unsigned long long c_cand = 0, c_cyl = 0, c_valid = 0, c_wrong = 0;
+  const uint32_t produced = p.ctrl[0];
+  const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
+  const int nsub = p.ssaa * p.ssaa;
+  const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
+  while (true) {
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(&p.ctrl[1], 1u);
+    c = __builtin_amdgcn_readfirstlane(c);
+    if (c >= n_items) break;              // every wave reaches this: the counter only grows
+    const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
+    const int group = (int)it[0];
+    const uint32_t start = it[1];
+    const int n = (int)it[2];
+    const int tile = group / nsub;
+    const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
+    // 1. lanes test 64 candidates of the macro list at a time against this tile's pyramid
+    V3 pl[4];
+    tile_planes(p, tx, tk, pl);
+    int ns = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int k = base + lane;
+      bool touch = false;
+      uint32_t sidx = 0;
+      if (k < n) {
+        sidx = p.bin_list[start + k];
+        touch = axis_touches_pyramid(p.capA[sidx], p.capB[sidx], pl);
+      }
+      const unsigned long long mask = __ballot(touch);
+      if (touch) surv[ns + (int)lanes_below(mask)] = sidx;
+      ns += __builtin_popcountll(mask);
+    }
+    __syncthreads();
+    // 2. every lane evaluates its own ray against each survivor (wave-uniform record, scalar loads)
+    const float* rr = p.rays + (size_t)group * 8 * 64;
+    Ray r;
+    r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+    r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
+    r.maxd = rr[6 * 64 + lane];
+    r.active = r.maxd >= 0.0f;
+    unsigned long long ai[3] = {0ull, 0ull, 0ull};
+    uint32_t nc = 0;
+    for (int k = 0; k < ns; ++k) {
+      const int sidx = __builtin_amdgcn_readfirstlane((int)surv[k]);
+      const SegFrame f = pb_uniform(p.frames)[sidx];
+      double integral = 0.0;
+      const int res = PRECISE ? eval_pair_721(f, r, p.extinction_c, integral)
+                              : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, integral, c_wrong);
+      if (res == 2) {
+        ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
+        ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[1], integral, PB_FIX_MAGIC));
+        ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[2], integral, PB_FIX_MAGIC));
+        nc++;
+      }
+      if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
+    }
+    __syncthreads();   // surv is rewritten by the next item
+    if (nc) {
+      const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
+      unsigned long long* dst = p.accum + ((size_t)oy * p.out_w + ox) * 3;   // active lanes are inside the image
+      const unsigned long long bias = (unsigned long long)nc * magic_bits;
+      atomicAdd(&dst[0], ai[0] - bias);
+      atomicAdd(&dst[1], ai[1] - bias);
+      atomicAdd(&dst[2], ai[2] - bias);
+    }
+  }
+  if (COUNT) {
+    unsigned long long v[4] = {c_cand, c_cyl, c_valid, c_wrong};
+    const int slot[4] = {PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_SHORTCUT_WRONG};
+    for (int k = 0; k < 4; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)p.out_w * p.out_h;
+  if (i >= n) return;
+  const double inv = PB_FIX_SCALE / (double)p.ssaa;      // skeleton.cpp:361: current / (double) SSAA
+  for (int k = 0; k < 3; ++k) {
+    const long long v = (long long)p.accum[i * 3 + k];
+    p.out[i * 3 + k] = (float)((double)v * inv);
+  }
+}
+
 }  // namespace
 
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
@@ -502,6 +801,44 @@ int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream
   else if (p.precise) hipLaunchKernelGGL((eval_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
   else hipLaunchKernelGGL((eval_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
   hipLaunchKernelGGL(reduce_kernel, dim3(tiles), dim3(64), 0, s, p);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}
+
+int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
+  const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
+  if (groups <= 0) return PB_OK;
+  if (count) hipLaunchKernelGGL(ray_setup_kernel<true>, dim3(groups), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(ray_setup_kernel<false>, dim3(groups), dim3(64), 0, s, p);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}
+
+// count pass, then the two prefix sums (entries per tile -> tile_off, ctrl[2] = total entries;
+// items per tile -> item_off, ctrl[0] = total items)
+int pb_launch_bin_count(const RenderParams& p, hipStream_t s) {
+  const int tiles = p.tiles_x * p.tiles_y;
+  if (tiles <= 0) return PB_OK;
+  if (p.n_seg > 0) hipLaunchKernelGGL(bin_kernel<false>, dim3((p.n_seg + 255) / 256), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(tile_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}
+
+int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s) {
+  if (mode != PB_MODE_721) { pb_set_error("pb_render: only PB_MODE_721 is implemented"); return PB_ERR_ARG; }
+  const int tiles = p.tiles_x * p.tiles_y;
+  if (tiles <= 0) return PB_OK;
+  if (p.n_seg > 0) hipLaunchKernelGGL(bin_kernel<true>, dim3((p.n_seg + 255) / 256), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(make_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
+  int waves = p.item_capacity < PB_EVAL_WAVES ? p.item_capacity : PB_EVAL_WAVES;
+  if (waves < 1) waves = 1;
+  if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
+  else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
+  else if (p.precise) hipLaunchKernelGGL((eval_bins_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL((eval_bins_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
+  const size_t px = (size_t)p.out_w * p.out_h;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, p);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }

@@ -99,6 +99,8 @@ def test_render_of_gpu_emitted_set_matches_oracle(pb):
         segs = ctx.download_segments()
         lo, hi = ctx.root_box()
         img = ctx.draw().astype(np.float64)
+        img_bins = ctx.draw(cull="bins").astype(np.float64)
+    np.testing.assert_allclose(img_bins, img, rtol=1e-5, atol=1e-7)
     tri, _ = orc.load_test_model()
     octl = orc.control_defaults(photon_number=2000, bounces=2)
     ref, cnt = orc.render_segments(octl, orc.tri_xyz(tri), orc.transformation_matrix(), segs, lo, hi,

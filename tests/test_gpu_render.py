@@ -60,8 +60,25 @@ def test_config1_tree_segments_full_frame(pb, cfg1, golden_dir):
         ctx.set_precise(False)
         ctx.build_tree()
         img_lbvh = ctx.draw(use_lbvh=True)
+        # screen-space bins + fixed-point sums: same pairs, order-independent, reproducible bit for bit
+        img_bins = ctx.draw(cull="bins")
+        ctx.enable_counters(True)
+        img_bins2 = ctx.draw(cull="bins")
+        cnt_bins = ctx.counters()
+        ctx.set_precise(True)
+        img_bins_precise = ctx.draw(cull="bins")
+        cnt_bins_precise = ctx.counters()
+        ctx.set_precise(False)
+        ctx.enable_counters(False)
     maxerr, rmse = check_radiance(img, ref, "config 1")
     check_radiance(img_lbvh, ref, "config 1 through the LBVH")
+    berr, brmse = check_radiance(img_bins, ref, "config 1 through screen bins")
+    bperr, _ = check_radiance(img_bins_precise, ref, "config 1 through screen bins, exact operation order")
+    print(f"config 1 bins: max-abs {berr:.3e} rmse {brmse:.3e}; exact order {bperr:.3e}; counters {cnt_bins}")
+    assert np.array_equal(img_bins, img_bins2)
+    assert bperr < 1e-4
+    assert cnt_bins_precise["valid_hits"] == 3144103 and cnt_bins["shortcut_wrong"] == 0
+    assert cnt_bins["valid_hits"] == cnt["valid_hits"]
     perr, prmse = check_radiance(img_precise, ref, "config 1, exact operation order")
     print(f"config 1: fast max-abs {maxerr:.3e} rmse {rmse:.3e}; exact-order max-abs {perr:.3e} rmse {prmse:.3e}")
     print("counters", cnt)
@@ -96,9 +113,12 @@ def test_ragged_rectangles_and_strips(pb, cfg1):
         ctx.set_scene()
         ctx.upload_segments(segs, lo, hi)
         full = ctx.draw()
+        full_bins = ctx.draw(cull="bins")
         for (x0, y0, w, h) in [(250, 90, 13, 5), (0, 0, 1, 1), (505, 500, 7, 12), (256, 93, 9, 1)]:
             part = ctx.draw(x0, y0, w, h)
             assert np.array_equal(part, full[y0:y0 + h, x0:x0 + w]), (x0, y0, w, h)
+            part = ctx.draw(x0, y0, w, h, cull="bins")
+            assert np.array_equal(part, full_bins[y0:y0 + h, x0:x0 + w]), ("bins", x0, y0, w, h)
         out = torch.zeros((8 * 16, 512, 3), dtype=torch.float32, device="cuda")
         ctx.draw_strips_device(out.data_ptr(), 3, 4, 16, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -106,6 +126,12 @@ def test_ragged_rectangles_and_strips(pb, cfg1):
         for k in range(16):
             y = 8 * (3 + 4 * k)
             assert np.array_equal(got[8 * k:8 * k + 8], full[y:y + 8]), k
+        ctx.draw_strips_device(out.data_ptr(), 1, 8, 8, stream=torch.cuda.current_stream().cuda_stream, cull="bins")
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for k in range(8):
+            y = 8 * (1 + 8 * k)
+            assert np.array_equal(got[8 * k:8 * k + 8], full_bins[y:y + 8]), ("bins", k)
 
 
 def test_empty_segment_set_and_errors(pb):
@@ -117,6 +143,8 @@ def test_empty_segment_set_and_errors(pb):
             ctx.draw()                               # no segments yet
         ctx.upload_segments(np.zeros(0, pb.SEGMENT_DTYPE), [-1, -1, 1], [1, 1, 4])
         img = ctx.draw()
+        assert img.shape == (64, 64, 3) and not img.any()
+        img = ctx.draw(cull="bins")
         assert img.shape == (64, 64, 3) and not img.any()
         with pytest.raises(pb.PhotonBeamsError):
             ctx.draw(0, 0, 65, 1)                    # rectangle exceeds the screen
