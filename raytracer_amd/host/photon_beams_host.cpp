@@ -1,0 +1,236 @@
+// See photon_beams_host.h.  Host glue only: every computation of the path happens in libphoton_beams.so.
+#include "photon_beams_host.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+namespace pbhost {
+
+vec4 light_position{0, (float)-0.8, (float)-0.5, 1};
+vec3 light_power{0.5f, 0.5f, 0.5f};
+float absorption_c = (float)0.035;
+float scattering_c = (float)0.005;
+float extinction_c = absorption_c + scattering_c;
+vec4 camera{0, 0, -3, 1.0f};
+vec3 theta{0.0f, 0.0f, 0.0f};
+pb_control control = [] { pb_control c; pb_control_defaults(&c); return c; }();
+
+namespace {
+
+pb_ctx* g_ctx = nullptr;
+std::vector<pb_beam> g_beams;      // beams_const list, then beams_scattered list
+int g_n_const = 0, g_n_scatt = 0;
+std::vector<pb_segment> g_segs;    // segments of the last photon pass, const part then scattered part
+int g_bound_calls = 0;
+std::vector<Triangle> g_triangles;
+
+void check(int rc, const char* what) {
+  if (rc != PB_OK) throw std::runtime_error(std::string(what) + ": " + pb_last_error());
+}
+
+pb_control current_control() {
+  pb_control c = control;
+  std::memcpy(c.light_position, &light_position, sizeof(float) * 4);
+  std::memcpy(c.light_power, &light_power, sizeof(float) * 3);
+  c.absorption_c = absorption_c; c.scattering_c = scattering_c;
+  std::memcpy(c.camera, &camera, sizeof(float) * 4);
+  std::memcpy(c.theta, &theta, sizeof(float) * 3);
+  return c;
+}
+
+pb_ctx* context() {
+  if (!g_ctx) check(pb_create(&control, 0, &g_ctx), "pb_create");
+  return g_ctx;
+}
+
+void recreate_context_if_control_changed() {
+  static pb_control last = control;
+  pb_control now = current_control();
+  if (g_ctx && std::memcmp(&last, &now, sizeof(now)) != 0) { pb_destroy(g_ctx); g_ctx = nullptr; }
+  control = now;
+  last = now;
+}
+
+vec4 v4(const float* p) { return vec4{p[0], p[1], p[2], p[3]}; }
+
+}  // namespace
+
+void LoadTestModel(std::vector<Triangle>& triangles) {
+  float tri[30 * 9], nrm[30 * 3];
+  int n = pb_load_test_model(tri, nrm, 30);
+  if (n != 30) throw std::runtime_error("pb_load_test_model failed");
+  // TestModelH.h:51-57, :101-184: white ceiling/floor/back, green left, red right, red short block, blue tall block
+  const vec3 red{0.75f, 0.15f, 0.15f}, green{0.15f, 0.75f, 0.15f}, blue{0.15f, 0.15f, 0.75f}, white{0.75f, 0.75f, 0.75f};
+  triangles.clear();
+  for (int i = 0; i < n; ++i) {
+    Triangle t;
+    t.v0 = vec4{tri[i * 9 + 0], tri[i * 9 + 1], tri[i * 9 + 2], 1.0f};
+    t.v1 = vec4{tri[i * 9 + 3], tri[i * 9 + 4], tri[i * 9 + 5], 1.0f};
+    t.v2 = vec4{tri[i * 9 + 6], tri[i * 9 + 7], tri[i * 9 + 8], 1.0f};
+    t.normal = vec4{nrm[i * 3], nrm[i * 3 + 1], nrm[i * 3 + 2], 1.0f};
+    t.colour = (i < 4) ? white : (i < 6) ? green : (i < 8) ? red : (i < 10) ? white : (i < 20) ? red : blue;
+    t.water = false; t.reflective = false;
+    triangles.push_back(t);
+  }
+}
+
+void TransformationMatrix(mat4& M) {
+  float th[3] = {theta.x, theta.y, theta.z}, cam[4] = {camera.x, camera.y, camera.z, camera.w};
+  pb_transformation_matrix(th, cam, &M.m[0][0]);
+}
+
+AABB CastPhotonBeams(int number, std::vector<PhotonBeam>& beams_const, std::vector<PhotonBeam>& beams_scattered,
+                     const mat4& matrix, const std::vector<Triangle>& triangles) {
+  extinction_c = absorption_c + scattering_c;
+  recreate_context_if_control_changed();
+  pb_ctx* ctx = context();
+  std::vector<float> tri(triangles.size() * 9);
+  for (size_t i = 0; i < triangles.size(); ++i) {
+    const vec4* v[3] = {&triangles[i].v0, &triangles[i].v1, &triangles[i].v2};
+    for (int k = 0; k < 3; ++k) { tri[i * 9 + k * 3] = v[k]->x; tri[i * 9 + k * 3 + 1] = v[k]->y; tri[i * 9 + k * 3 + 2] = v[k]->z; }
+  }
+  g_triangles = triangles;
+  check(pb_set_scene(ctx, tri.data(), (int)triangles.size(), &matrix.m[0][0]), "pb_set_scene");
+  int n_beams = 0, n_segs = 0;
+  check(pb_emit_beams(ctx, number, control.seed, &n_beams, &n_segs), "pb_emit_beams");
+  check(pb_beam_counts(ctx, &g_n_const, &g_n_scatt), "pb_beam_counts");
+  g_beams.resize((size_t)(n_beams > 0 ? n_beams : 1));
+  int got = 0;
+  check(pb_download_beams(ctx, g_beams.data(), (int)g_beams.size(), &got), "pb_download_beams");
+  g_beams.resize((size_t)got);
+  g_segs.resize((size_t)(n_segs > 0 ? n_segs : 1));
+  check(pb_download_segments(ctx, g_segs.data(), (int)g_segs.size(), &got), "pb_download_segments");
+  g_segs.resize((size_t)got);
+  g_bound_calls = 0;
+  for (int i = 0; i < (int)g_beams.size(); ++i) {
+    const pb_beam& b = g_beams[i];
+    PhotonBeam o;
+    o.start = v4(b.start); o.end = v4(b.end); o.omega_u = v4(b.omega_u); o.omega_v = v4(b.omega_u);
+    o.ada_width = (b.flags & 1u) != 0; o.offset = 0.0f; o.radius = b.radius;
+    o.energy = dvec3{b.energy[0], b.energy[1], b.energy[2]};
+    o.index_hit = b.index_hit; o.absorbed = (b.flags & 4u) != 0; o.scattered = (b.flags & 2u) != 0;
+    (i < g_n_const ? beams_const : beams_scattered).push_back(o);
+  }
+  float lo[3], hi[3];
+  check(pb_get_root_box(ctx, lo, hi), "pb_get_root_box");
+  AABB root;   // CastPhotons.h:384-387: z stored flipped
+  root.min = vec4{lo[0], lo[1], hi[2], 1}; root.max = vec4{hi[0], hi[1], lo[2], 1};
+  root.mid = vec4{(root.min.x + root.max.x) / 2.0f, (root.min.y + root.max.y) / 2.0f, (root.min.z + root.max.z) / 2.0f, 1};
+  return root;
+}
+
+void BoundPhotonBeams(std::vector<PhotonBeam>& beams, std::vector<PhotonSeg>& items, const std::vector<Triangle>&) {
+  // segments of the const list come first; PhotonSeg.id restarts at 0 for the scattered list (CastPhotons.h:227)
+  size_t split = g_segs.size();
+  for (size_t i = 1; i < g_segs.size(); ++i)
+    if (g_segs[i].id < g_segs[i - 1].id) { split = i; break; }
+  const bool first = (g_bound_calls++ == 0) && ((int)beams.size() == g_n_const);
+  const size_t a = first ? 0 : split, b = first ? split : g_segs.size();
+  for (size_t i = a; i < b; ++i) {
+    const pb_segment& s = g_segs[i];
+    PhotonSeg o;
+    o.start = vec4{s.start[0], s.start[1], s.start[2], 1}; o.end = vec4{s.end[0], s.end[1], s.end[2], 1};
+    o.orig_start = vec4{s.orig_start[0], s.orig_start[1], s.orig_start[2], 1};
+    o.min = vec4{s.cull_lo[0], s.cull_lo[1], s.cull_hi[2], 1};   // PhotonSeg.min/max keep z flipped
+    o.max = vec4{s.cull_hi[0], s.cull_hi[1], s.cull_lo[2], 1};
+    o.mid = vec4{(o.min.x + o.max.x) / 2.0f, (o.min.y + o.max.y) / 2.0f, (o.min.z + o.max.z) / 2.0f, 1};
+    o.radius = s.radius; o.ada_width = (s.flags & 1u) != 0; o.id = s.id;
+    o.s_ext = s.s_ext; o.e_ext = s.e_ext; o.c_ext = s.c_ext; o.seg_id = s.seg_id; o.scattered = (s.flags & 2u) != 0;
+    items.push_back(o);
+  }
+}
+
+Node* newNode(AABB data) {
+  Node* n = new Node;
+  n->aabb = data; n->leaf = false;
+  return n;
+}
+
+void BuildTree(Node* parent, std::vector<PhotonSeg>& child, int) {
+  pb_ctx* ctx = context();
+  std::vector<pb_segment> segs(child.size());
+  for (size_t i = 0; i < child.size(); ++i) {
+    const PhotonSeg& s = child[i];
+    pb_segment& d = segs[i];
+    std::memset(&d, 0, sizeof(d));
+    d.start[0] = s.start.x; d.start[1] = s.start.y; d.start[2] = s.start.z;
+    d.end[0] = s.end.x; d.end[1] = s.end.y; d.end[2] = s.end.z;
+    d.orig_start[0] = s.orig_start.x; d.orig_start[1] = s.orig_start.y; d.orig_start[2] = s.orig_start.z;
+    d.radius = s.radius;
+    d.cull_lo[0] = s.min.x; d.cull_lo[1] = s.min.y; d.cull_lo[2] = s.max.z;
+    d.cull_hi[0] = s.max.x; d.cull_hi[1] = s.max.y; d.cull_hi[2] = s.min.z;
+    // BeamRadiance.h:449-455 with seg.scattered always false (CastPhotons.h:398): beams_const[seg.id]
+    const int list0 = s.scattered ? g_n_const : 0, listn = s.scattered ? g_n_scatt : g_n_const;
+    if (s.id >= 0 && s.id < listn) std::memcpy(d.energy, g_beams[(size_t)(list0 + s.id)].energy, sizeof(float) * 3);
+    d.s_ext = s.s_ext; d.e_ext = s.e_ext; d.c_ext = s.c_ext; d.seg_id = s.seg_id; d.id = s.id;
+    d.flags = (s.ada_width ? 1u : 0u) | (s.scattered ? 2u : 0u);
+  }
+  const AABB& r = parent->aabb;   // un-flip: min_b = (min.x, min.y, max.z), Intersections.h:85-86
+  const float lo[3] = {r.min.x, r.min.y, r.max.z}, hi[3] = {r.max.x, r.max.y, r.min.z};
+  check(pb_upload_segments(ctx, segs.data(), (int)segs.size(), lo, hi), "pb_upload_segments");
+  check(pb_build_lbvh(ctx), "pb_build_lbvh");
+  parent->leaf = child.size() <= 2;
+}
+
+screen* InitializeSDL(int width, int height, bool) {
+  screen* s = new screen;
+  s->width = width; s->height = height;
+  s->buffer = new uint32_t[(size_t)width * height];
+  std::memset(s->buffer, 0, sizeof(uint32_t) * (size_t)width * height);
+  return s;
+}
+
+void PutPixelSDL(screen* s, int x, int y, vec3 colour) {
+  if (x < 0 || x >= s->width || y < 0 || y >= s->height) return;
+  const float rgb[3] = {colour.x, colour.y, colour.z};
+  pb_quantise_argb(rgb, 1, &s->buffer[(size_t)y * s->width + x]);
+}
+
+void SDL_Renderframe(screen*) {}
+
+// 32-bit BMP with BI_BITFIELDS masks (A 0xff000000, R 0x00ff0000, G 0x0000ff00, B 0x000000ff), bottom-up,
+// as SDL_SaveBMP writes an ARGB8888 surface.
+void SDL_SaveImage(screen* s, const char* filename) {
+  const uint32_t w = (uint32_t)s->width, h = (uint32_t)s->height, data = w * h * 4, off = 14 + 108;
+  unsigned char hdr[14 + 108];
+  std::memset(hdr, 0, sizeof(hdr));
+  auto put32 = [&](int at, uint32_t v) { for (int k = 0; k < 4; ++k) hdr[at + k] = (unsigned char)(v >> (8 * k)); };
+  auto put16 = [&](int at, uint32_t v) { hdr[at] = (unsigned char)v; hdr[at + 1] = (unsigned char)(v >> 8); };
+  hdr[0] = 'B'; hdr[1] = 'M'; put32(2, off + data); put32(10, off);
+  put32(14, 108); put32(18, w); put32(22, h); put16(26, 1); put16(28, 32); put32(30, 3); put32(34, data);
+  put32(38, 2835); put32(42, 2835);
+  put32(54, 0x00ff0000u); put32(58, 0x0000ff00u); put32(62, 0x000000ffu); put32(66, 0xff000000u);
+  put32(70, 0x57696e20u);   // "Win " colour space
+  FILE* f = std::fopen(filename, "wb");
+  if (!f) throw std::runtime_error(std::string("cannot write ") + filename);
+  std::fwrite(hdr, 1, sizeof(hdr), f);
+  for (int y = s->height - 1; y >= 0; --y) std::fwrite(s->buffer + (size_t)y * s->width, 4, (size_t)s->width, f);
+  std::fclose(f);
+}
+
+void KillSDL(screen* s) {
+  delete[] s->buffer;
+  delete s;
+}
+
+void DrawStandard(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>) {
+  pb_ctx* ctx = context();
+  std::vector<float> rgb((size_t)scr->width * scr->height * 3);
+  check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_721, /*screen bins*/ 2, rgb.data()), "pb_render");
+  check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
+}
+
+pb_stats Stats() {
+  pb_stats s;
+  check(pb_counters(context(), &s), "pb_counters");
+  return s;
+}
+
+void Shutdown() {
+  if (g_ctx) { pb_destroy(g_ctx); g_ctx = nullptr; }
+}
+
+}  // namespace pbhost

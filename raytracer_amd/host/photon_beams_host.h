@@ -1,0 +1,86 @@
+// C++ host layer with the reference's own function names, argument lists and globals for the photon-beam
+// path, implemented on the C ABI of include/photon_beams.h.  A program written against the reference's
+// headers (skeleton.cpp's StandardRun) compiles against this header instead of CastPhotons.h /
+// BeamRadiance.h / SDLauxiliary.h and runs the path on the GPU.  Vector types are plain structs with
+// glm's memory layout (column-major matrices); no glm, no SDL.
+//
+// Differences a caller can observe, all stated where they arise:
+//  * CastPhotonBeams draws counter-based random numbers per photon instead of one std::mt19937 stream
+//    (CastPhotons.h:86): same distribution, different beams for a given SEED.
+//  * BuildTree builds a linear BVH; Node is an opaque handle (the reference's tree only influences the
+//    image through each segment's gate box, which is PhotonSeg.min/max here).
+//  * The display functions are headless: InitializeSDL allocates the ARGB buffer, SDL_Renderframe does
+//    nothing, SDL_SaveImage writes a 32-bit BMP.
+//  * Errors: the reference prints and exit(1)s only in its SDL code; here every failing GPU call throws
+//    std::runtime_error carrying pb_last_error().
+#ifndef PHOTON_BEAMS_HOST_H
+#define PHOTON_BEAMS_HOST_H
+#include <cstdint>
+#include <vector>
+
+#include "../../include/photon_beams.h"
+
+namespace pbhost {
+
+struct vec3 { float x, y, z; };
+struct vec4 { float x, y, z, w; };
+struct dvec3 { double x, y, z; };
+struct mat4 { float m[4][4]; };   // m[col][row], as glm::mat4
+
+// Control.h:40-50, skeleton.cpp:25 — the mutable globals the reference's functions read.
+extern vec4 light_position;
+extern vec3 light_power;
+extern float absorption_c, scattering_c, extinction_c;
+extern vec4 camera;
+extern vec3 theta;
+// Control.h:4-31 — compile-time switches there, run-time values here (same names, lower case).
+extern pb_control control;
+
+struct Triangle {                 // TestModelH.h:12-39
+  vec4 v0, v1, v2, normal;
+  vec3 colour;
+  bool water, reflective;
+};
+struct Intersection { vec4 position; float distance; int index; bool water; };   // Intersections.h:7-13
+struct AABB { vec4 max, min, mid; };                                             // Intersections.h:28-33 (z flipped)
+struct PhotonSeg {                                                               // Intersections.h:36-52
+  vec4 start, end, mid, min, max, orig_start;
+  float radius; bool ada_width; int id; float s_ext, e_ext, c_ext; int seg_id; bool scattered;
+};
+struct PhotonBeam {                                                              // CastPhotons.h:14-27
+  vec4 start, end, omega_u, omega_v;
+  bool ada_width; float offset, radius; dvec3 energy; int index_hit; bool absorbed, scattered;
+};
+struct Node { AABB aabb; bool leaf; };   // CastPhotons.h:49-56: handle only, the hierarchy lives on the GPU
+struct screen { int height, width; uint32_t* buffer; };                          // SDLauxiliary.h:9-16
+
+void LoadTestModel(std::vector<Triangle>& triangles);                            // TestModelH.h:45
+void TransformationMatrix(mat4& M);                                              // skeleton.cpp:512
+
+AABB CastPhotonBeams(int number, std::vector<PhotonBeam>& beams_const, std::vector<PhotonBeam>& beams_scattered,
+                     const mat4& matrix, const std::vector<Triangle>& triangles);   // CastPhotons.h:99-103
+// Appends the segments of `beams` (the list of that size returned by the last CastPhotonBeams).
+void BoundPhotonBeams(std::vector<PhotonBeam>& beams, std::vector<PhotonSeg>& items,
+                      const std::vector<Triangle>& triangles);                       // CastPhotons.h:107
+Node* newNode(AABB data);                                                            // CastPhotons.h:58
+// Makes `child` the segment set to render (gate box = PhotonSeg.min/max, energy looked up as
+// BeamRadiance.h:449-455 does) and builds the acceleration structure over it.
+void BuildTree(Node* parent, std::vector<PhotonSeg>& child, int leftover);           // CastPhotons.h:105
+
+screen* InitializeSDL(int width, int height, bool fullscreen = false);               // SDLauxiliary.h:72
+void PutPixelSDL(screen* s, int x, int y, vec3 colour);                              // SDLauxiliary.h:149
+void SDL_Renderframe(screen* s);                                                     // SDLauxiliary.h:64
+void SDL_SaveImage(screen* s, const char* filename);                                 // SDLauxiliary.h:24
+void KillSDL(screen* s);                                                             // SDLauxiliary.h:55
+
+// One frame of skeleton.cpp:330-365 on the GPU; uses the tree of the last BuildTree as the reference
+// uses its global `root`.
+void DrawStandard(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scatt);
+
+// Counters and device times of the last calls (pb_counters).
+pb_stats Stats();
+// Releases the GPU context (the reference leaks its tree; a long-running host may not want to).
+void Shutdown();
+
+}  // namespace pbhost
+#endif

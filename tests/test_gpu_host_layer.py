@@ -1,0 +1,45 @@
+"""The C++ host layer with the reference's function names (raytracer_amd/host) driving StandardRun
+(examples/skeleton_headless.cpp) must produce the very image the C ABI gives when driven directly."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "skeleton_headless")
+
+
+def read_bmp32(path):
+    raw = open(path, "rb").read()
+    assert raw[:2] == b"BM"
+    off = struct.unpack_from("<I", raw, 10)[0]
+    w, h = struct.unpack_from("<ii", raw, 18)
+    bpp = struct.unpack_from("<H", raw, 28)[0]
+    assert bpp == 32 and h > 0
+    px = np.frombuffer(raw, dtype="<u4", count=w * h, offset=off).reshape(h, w)
+    return px[::-1].copy()        # bottom-up file -> top-down image
+
+
+def test_standard_run_through_reference_named_functions(tmp_path):
+    import raytracer_amd as pb
+    if pb.device_count() < 1:
+        pytest.fail("no GPU visible")
+    assert os.path.exists(EXE), "examples/skeleton_headless is not built (make -C raytracer_amd/csrc)"
+    out = str(tmp_path / "shot.bmp")
+    r = subprocess.run([EXE, "2000", "2", "256", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert "Beams size:" in r.stdout and "Render time:" in r.stdout
+    img = read_bmp32(out)
+    assert img.shape == (256, 256) and (img >> 24 == 128).all()
+    with pb.Context(pb.control_defaults(photon_number=2000, bounces=2, screen_width=256, screen_height=256)) as ctx:
+        ctx.set_scene()
+        n_beams, n_segs = ctx.cast_photon_beams()
+        ref = pb.quantise_argb(ctx.draw(cull="bins"))
+    assert f"Beams size: {n_beams}" in r.stdout and f"Segment size: {n_segs}" in r.stdout
+    assert np.array_equal(img, ref)
+    assert (img & 0xFF).max() > 100
