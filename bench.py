@@ -80,6 +80,7 @@ def main():
     import torch
     import torch.distributed as dist
     import raytracer_amd as pb
+    from raytracer_amd import tiles
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,16 +110,11 @@ def main():
         segs = ctx.download_segments()
         root = np.concatenate(ctx.root_box()).astype(np.float32)
     if world > 1:
-        meta = torch.zeros(8, dtype=torch.float32, device=dev)
-        if rank == 0:
-            meta[:6] = torch.from_numpy(root); meta[6] = float(len(segs)); meta[7] = float(n_beams)
-        dist.broadcast(meta, 0)
-        n_segs = int(meta[6].item()); n_beams = int(meta[7].item())
-        buf = torch.empty(n_segs * pb.SEGMENT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            buf.copy_(torch.from_numpy(segs.view(np.uint8)))
-        dist.broadcast(buf, 0)                      # RCCL broadcast of the segment records
-        root = meta[:6].cpu().numpy()
+        buf, n_segs, root = tiles.broadcast_segments(segs if rank == 0 else None, root if rank == 0 else None, dev,
+                                                     itemsize=pb.SEGMENT_DTYPE.itemsize)   # RCCL broadcast
+        nb = torch.tensor([n_beams if rank == 0 else 0], device=dev)
+        dist.broadcast(nb, 0)
+        n_beams = int(nb.item())
         torch.cuda.synchronize()
         if rank != 0:
             ctx.upload_segments_device(buf.data_ptr(), n_segs, root[:3], root[3:],
@@ -128,9 +124,7 @@ def main():
     ctx.build_tree()     # the LBVH is part of the photon pass whichever cull mode renders (ms_build)
 
     # ---- strips of this rank ----
-    n_strips_total = H // 8
-    assert H % 8 == 0 and n_strips_total % world == 0, "image height must split into 8-row strips per rank"
-    n_my = n_strips_total // world
+    first_strip, strip_stride, n_my = tiles.strips_of_rank(H, rank, world)
     mine = torch.zeros((n_my * 8, W, 3), dtype=torch.float32, device=dev)
     gathered = torch.zeros((world, n_my * 8, W, 3), dtype=torch.float32, device=dev) if world > 1 else None
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
@@ -141,15 +135,10 @@ def main():
     def step(i=None):
         if i is not None:
             ev0[i].record()
-        ctx.draw_strips_device(mine.data_ptr(), rank, world, n_my, cull=cull, stream=stream)
+        ctx.draw_strips_device(mine.data_ptr(), first_strip, strip_stride, n_my, cull=cull, stream=stream)
         if i is not None:
             ev1[i].record()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, mine)      # RCCL all-gather of the row tiles
-            # strip s of the image is strip s // world of rank s % world
-            frame.view(n_my, world, 8, W, 3).copy_(gathered.view(world, n_my, 8, W, 3).transpose(0, 1))
-        else:
-            frame.copy_(mine)
+        tiles.gather_frame(mine, gathered, frame, world)     # RCCL all-gather of the row tiles + reorder
 
     for _ in range(args.warmup):
         step()

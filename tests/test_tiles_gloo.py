@@ -1,0 +1,76 @@
+"""The N > 1 path of bench.py on CPU: two and four gloo ranks shard a frame into interleaved strips,
+all-gather them and reassemble the image; the segment broadcast carries the records byte for byte."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd import tiles
+
+SEG_DTYPE = np.dtype([("raw", "u1", 112)])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, height, width, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the "renderer": pixel (y, x, c) = 1000*y + x + c/10, so every misplaced row shows
+        yy, xx, cc = np.meshgrid(np.arange(height), np.arange(width), np.arange(3), indexing="ij")
+        full = (1000.0 * yy + xx + cc / 10.0).astype(np.float32)
+        rows = tiles.rows_of_rank(height, rank, world)
+        first, stride, n = tiles.strips_of_rank(height, rank, world)
+        assert (first, stride) == (rank, world) and len(rows) == n * 8
+        mine = torch.from_numpy(full[rows].copy())
+        gathered = torch.zeros((world, n * 8, width, 3), dtype=torch.float32)
+        frame = torch.zeros((height, width, 3), dtype=torch.float32)
+        tiles.gather_frame(mine, gathered, frame, world)
+        assert np.array_equal(frame.numpy(), full), "reassembled frame differs"
+        # segment broadcast
+        segs = None
+        root = None
+        if rank == 0:
+            rng = np.random.default_rng(5)
+            segs = np.zeros(777, SEG_DTYPE)
+            segs["raw"] = rng.integers(0, 256, (777, 112), dtype=np.uint8)
+            root = [-1, -1, 1.5, 1, 1, 3.5]
+        buf, n_seg, root_box = tiles.broadcast_segments(segs, root, torch.device("cpu"))
+        assert n_seg == 777 and np.allclose(root_box, [-1, -1, 1.5, 1, 1, 3.5])
+        ref = np.random.default_rng(5).integers(0, 256, (777, 112), dtype=np.uint8)
+        assert np.array_equal(buf.numpy()[:777 * 112].reshape(777, 112), ref)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strips_gather_and_broadcast_over_gloo(world, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, 64, 40, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), f"ok{r}")) for r in range(world))
+
+
+def test_strip_bookkeeping():
+    assert tiles.strips_of_rank(512, 3, 8) == (3, 8, 8)
+    rows = np.concatenate([tiles.rows_of_rank(64, r, 4) for r in range(4)])
+    assert sorted(rows.tolist()) == list(range(64))
+    assert tiles.rows_of_rank(64, 1, 4)[:9].tolist() == [8, 9, 10, 11, 12, 13, 14, 15, 40]
+    with pytest.raises(ValueError):
+        tiles.strips_of_rank(100, 0, 2)
+    with pytest.raises(ValueError):
+        tiles.strips_of_rank(24, 0, 2)
+    g = torch.arange(2 * 16 * 3 * 1, dtype=torch.float32).view(2, 16, 3, 1)
+    f = tiles.assemble(g, torch.zeros(32, 3, 1))
+    assert torch.equal(f[8:16], g[1, :8]) and torch.equal(f[16:24], g[0, 8:])
