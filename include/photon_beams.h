@@ -149,9 +149,25 @@ void pb_transformation_matrix(const float theta[3], const float camera[4], float
  * receives on every call: triangles in world space, matrix as above. */
 int pb_set_scene(pb_ctx* ctx, const float* tri_xyz, int n_tri, const float matrix[16]);
 
-/* The extinction field GRID (Tessendorf.h:16-27) after HeterogeneousRun's
- * transform (skeleton.cpp:119-125): side*side values of sigma_t. */
+/* CreateSurface + UpdateHeight (Tessendorf.h:47-132): the (triangle_number+1)^2 points of
+ * GRID.geometric_points as xyzw, z = |sum of the wave spectrum| + height.  Host arithmetic only;
+ * returns the number of points, or a negative pb_status if capacity_points is too small. */
+int pb_create_surface(int triangle_number, float height, double time, float* points_xyzw, int capacity_points);
+
+/* matrix * point for n xyzw points in place, with glm's mat4 * vec4 operation order: the loop of
+ * HeterogeneousRun (skeleton.cpp:119-125) that moves GRID into camera space. */
+void pb_transform_points(const float matrix[16], float* points_xyzw, int n);
+
+/* The extinction field that Extinction3D reads (Heterogeneous.h:152-163): GRID.geometric_points[i].z
+ * after HeterogeneousRun's transform, side*side values, i = row * side + column, side = GRID.side_points. */
 int pb_set_grid(pb_ctx* ctx, const float* sigma_t, int side);
+
+/* Extinction3D (Heterogeneous.h:29-135) for n rays at once: start/end are xyz triples in camera space.
+ * mean_out[i] is the function's return value (mean of the samples), count_out[i] (optional) the number
+ * of (distance, extinction) samples, samples_out (optional) the first max_samples of them per ray as
+ * float pairs.  Cell indices outside the grid are clamped (the reference reads out of bounds there). */
+int pb_extinction3d(pb_ctx* ctx, const float* start_xyz, const float* end_xyz, int n, float* mean_out,
+                    int* count_out, float* samples_out, int max_samples);
 
 /* The segment set that BuildTree (CastPhotons.h:800-1126) would hold, and the
  * root box that CastPhotonBeams returns (CastPhotons.h:384-389, un-flipped).

@@ -101,6 +101,7 @@ def library():
         L.pb_destroy.restype = None
         L.pb_control_defaults.restype = None
         L.pb_transformation_matrix.restype = None
+        L.pb_transform_points.restype = None
         _lib = L
     return _lib
 
@@ -153,6 +154,26 @@ def transformation_matrix(theta=(0.0, 0.0, 0.0), camera=(0.0, 0.0, -3.0, 1.0)):
     m = np.zeros(16, np.float32)
     library().pb_transformation_matrix(_fp(_f32(theta, 3)), _fp(_f32(camera, 4)), _fp(m))
     return m
+
+
+def create_surface(triangle_number=27, height=-3.0, time=0.016):
+    """CreateSurface (Tessendorf.h:47-75): the (triangle_number+1)^2 lattice points as an (n, 4) array."""
+    side = triangle_number + 1
+    pts = np.zeros((side * side, 4), np.float32)
+    n = library().pb_create_surface(C.c_int(triangle_number), C.c_float(height), C.c_double(time), _fp(pts),
+                                    C.c_int(side * side))
+    if n != side * side:
+        raise PhotonBeamsError(f"pb_create_surface returned {n}")
+    return pts, side
+
+
+def make_grid(matrix=None, triangle_number=27, height=-3.0, time=0.016):
+    """HeterogeneousRun's grid set-up (skeleton.cpp:113-125): CreateSurface, then every point moved into
+    camera space; returns (sigma_t = z of the moved points, side)."""
+    pts, side = create_surface(triangle_number, height, time)
+    m = transformation_matrix() if matrix is None else _f32(matrix, 16)
+    library().pb_transform_points(_fp(m), _fp(pts), C.c_int(len(pts)))
+    return np.ascontiguousarray(pts[:, 2]), side
 
 
 def quantise_argb(rgb):
@@ -208,6 +229,19 @@ class Context:
         _check(self.L.pb_set_grid(self.h, _fp(s), C.c_int(side)), "pb_set_grid")
 
     # -- segments ------------------------------------------------------------
+    def extinction3d(self, starts, ends, max_samples=0):
+        """Extinction3D for rows of xyz start/end points: (means, counts[, samples (n, max_samples, 2)])."""
+        a = np.ascontiguousarray(starts, np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(ends, np.float32).reshape(-1, 3)
+        n = len(a)
+        mean = np.zeros(n, np.float32); cnt = np.zeros(n, np.int32)
+        samp = np.zeros((n, max_samples, 2), np.float32) if max_samples else None
+        _check(self.L.pb_extinction3d(self.h, _fp(a), _fp(b), C.c_int(n), _fp(mean),
+                                      cnt.ctypes.data_as(C.POINTER(C.c_int)),
+                                      _fp(samp) if samp is not None else None, C.c_int(max_samples)),
+               "pb_extinction3d")
+        return (mean, cnt, samp) if max_samples else (mean, cnt)
+
     def upload_segments(self, segs, root_lo, root_hi):
         """The segment set BuildTree would hold (CastPhotons.h:83, :808) and CastPhotonBeams' root box."""
         segs = np.ascontiguousarray(segs)

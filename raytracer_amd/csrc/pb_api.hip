@@ -42,11 +42,14 @@ int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
   if (ctx->d_frames) PB_HIP(hipFree(ctx->d_frames));
   if (ctx->d_capA) PB_HIP(hipFree(ctx->d_capA));
   if (ctx->d_capB) PB_HIP(hipFree(ctx->d_capB));
+  if (ctx->d_het) PB_HIP(hipFree(ctx->d_het));
+  ctx->d_het = nullptr;
   ctx->d_segs = nullptr; ctx->d_frames = nullptr; ctx->d_capA = nullptr; ctx->d_capB = nullptr; ctx->cap_seg = 0;
   PB_HIP(hipMalloc(&ctx->d_segs, sizeof(pb_segment) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_frames, sizeof(SegFrame) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_capA, sizeof(float4) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_capB, sizeof(float4) * (size_t)cap));
+  PB_HIP(hipMalloc(&ctx->d_het, sizeof(HetFrame) * (size_t)cap));
   ctx->cap_seg = cap;
   return PB_OK;
 }
@@ -62,7 +65,7 @@ int default_mode(const pb_ctx* ctx) {
 int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
   PB_HIP(hipEventRecord(ctx->ev[2], s));
   int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA,
-                                      ctx->d_capB, s);
+                                      ctx->d_capB, ctx->d_het, s);
   if (rc != PB_OK) return rc;
   PB_HIP(hipEventRecord(ctx->ev[3], s));
   ctx->ev_valid[1] = true;
@@ -203,6 +206,9 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.width = ctx->ctl.screen_width; p.height = ctx->ctl.screen_height; p.ssaa = ctx->ctl.ssaa;
   p.focal = (float)(ctx->ctl.screen_width * ctx->ctl.ssaa);      // rasteriser.h:17
   p.extinction_c = ctx->ctl.absorption_c + ctx->ctl.scattering_c; // Control.h:48
+  p.scattering_c = ctx->ctl.scattering_c;
+  p.het = ctx->d_het; p.grid_z = ctx->d_grid; p.grid_side = ctx->grid_side;
+  if (mode == PB_MODE_73HET && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_73HET needs pb_set_grid"); return PB_ERR_STATE; }
   p.x0 = x0; p.y0 = y0; p.out_w = out_w; p.out_h = out_h; p.strip_stride = strip_stride;
   p.tiles_x = (out_w + 7) / 8; p.tiles_y = (out_h + 7) / 8;
   p.out = d_out;
@@ -314,7 +320,7 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
-                  ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_rays, ctx->d_group_last,
+                  ctx->d_het, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_rays, ctx->d_group_last,
                   ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->d_tile_u32, ctx->d_bin_list, ctx->d_items, ctx->d_accum,
                   ctx->d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
                   ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};
@@ -356,9 +362,16 @@ int pb_set_scene(pb_ctx* ctx, const float* tri_xyz, int n_tri, const float matri
 }
 
 int pb_set_grid(pb_ctx* ctx, const float* sigma_t, int side) {
-  (void)ctx; (void)sigma_t; (void)side;
-  pb_set_error("pb_set_grid: the heterogeneous path is not implemented yet");
-  return PB_ERR_STATE;
+  if (!ctx || !sigma_t || side < 2 || side > 4096) { pb_set_error("pb_set_grid: bad argument (2 <= side <= 4096)"); return PB_ERR_ARG; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  if (ctx->d_grid) { PB_HIP(hipFree(ctx->d_grid)); ctx->d_grid = nullptr; ctx->grid_side = 0; }
+  const size_t n = (size_t)side * side;
+  PB_HIP(hipMalloc(&ctx->d_grid, sizeof(float) * n));
+  PB_HIP(hipMemcpyAsync(ctx->d_grid, sigma_t, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+  PB_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->grid_side = side;
+  return PB_OK;
 }
 
 static int upload_common(pb_ctx* ctx, const pb_segment* src, bool src_on_device, int n, const float root_lo[3],

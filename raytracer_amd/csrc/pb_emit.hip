@@ -13,6 +13,7 @@
 
 #include "pb_internal.h"
 #include "pb_geom.h"
+#include "pb_grid.h"
 #include "pb_scan.h"
 
 namespace {
@@ -64,6 +65,7 @@ struct EmitParams {
   pb_beam* beams_const;
   pb_beam* beams_scatt;
   unsigned int* dropped;      // scattering events dropped because the stack was full
+  GridView grid;              // extinction field; used when ctl.heterogeneous
 };
 
 // CastPhotons.h:1128-1141
@@ -95,7 +97,7 @@ PB_DI double transmittance(double length, double ext) { return exp(-ext * length
 struct Frame {
   V4 origin, direction, hit_pos;
   V3 energy;
-  float t_s, scattered, avg_ext;
+  float t_s, t_end, scattered, avg_ext;
   int bounce, parity, stage, hit_index;
   bool hit, scatt, ada;
 };
@@ -147,7 +149,10 @@ PB_DI void cast_beam(const EmitParams& p, Rng& rng, BeamSink& sink, Frame first,
         t_s = length3(xyz(pos) - xyz(F.origin));
         if (t_s < 0.0005) { sp--; continue; }
       } else t_s = PB_ACTUAL_WIDTH;
-      const float average_extinction = extinction_c;   // homogeneous medium (CastPhotons.h:414)
+      // CastPhotons.h:409-415: mean extinction along the way to the surface
+      const float t_end = t_s;
+      const V3 walk_a = xyz(F.origin), walk_b = xyz(F.origin + (F.direction * t_end));
+      const float average_extinction = C.heterogeneous ? extinction3d_mean(p.grid, walk_a, walk_b) : extinction_c;
       const float scattered = (float)rng.uniform();
       bool scatt = false, spawn = false;
       Frame child;
@@ -163,7 +168,9 @@ PB_DI void cast_beam(const EmitParams& p, Rng& rng, BeamSink& sink, Frame first,
           const float y = sinf(phi) * sinf(the);
           const float z = cosf(phi);
           const V3 dir = normalize3(v3(x, y, z));
-          const float transmitted = (float)transmittance(t_s, average_extinction);
+          // CastPhotons.h:436-447
+          const float transmitted = (float)transmittance(
+              t_s, C.heterogeneous ? extinction3d_mean_until(p.grid, walk_a, walk_b, t_s) : average_extinction);
           V3 ne = F.energy * transmitted;
           if (!(ne.x == 0 && ne.y == 0 && ne.z == 0)) {
             ne.x = fminf(F.energy.x, fmaxf(ne.x, 0.f));
@@ -184,7 +191,7 @@ PB_DI void cast_beam(const EmitParams& p, Rng& rng, BeamSink& sink, Frame first,
         const float tmp_t_s = (float)(-(log(1 - rng.uniform()) / average_extinction));
         if ((tmp_t_s < t_s) && (tmp_t_s > 0)) { sp--; continue; }   // absorbed in flight, never pushed (:469-479)
       }
-      F.t_s = t_s; F.scattered = scattered; F.avg_ext = average_extinction;
+      F.t_s = t_s; F.t_end = t_end; F.scattered = scattered; F.avg_ext = average_extinction;
       F.hit = hit; F.hit_pos = pos; F.hit_index = idx; F.scatt = scatt;
       F.stage = 1;
       if (spawn) {
@@ -214,7 +221,11 @@ PB_DI void cast_beam(const EmitParams& p, Rng& rng, BeamSink& sink, Frame first,
         const V3 bn = normalize3(xyz(bounce_dir));
         V4 new_direction = v4(bn.x, bn.y, bn.z, 1.0f);
         if (F.scattered > 0.8) new_direction = reflected;
-        const float transmitted = (float)transmittance(F.t_s, F.avg_ext);
+        // CastPhotons.h:529-540: the sample list is still the one of the walk to the surface
+        float ext_to_ts = F.avg_ext;
+        if (C.heterogeneous)
+          ext_to_ts = extinction3d_mean_until(p.grid, xyz(origin), xyz(origin + (direction * F.t_end)), F.t_s);
+        const float transmitted = (float)transmittance(F.t_s, ext_to_ts);
         V3 ne = energy * transmitted;
         if (!(ne.x == 0 && ne.y == 0 && ne.z == 0)) {
           ne.x = fminf(energy.x, fmaxf(ne.x, 0.f));
@@ -313,14 +324,18 @@ struct BoundParams {
   const pb_beam* beams;       // beams_const list then beams_scattered list
   int n_const, n_scatt;
   float extinction_c;
+  int heterogeneous;
+  GridView grid;
   uint32_t* seg_count;        // counting pass
   const uint32_t* seg_offset; // writing pass
   pb_segment* segs;
 };
 
-// BoundPhotonBeams (CastPhotons.h:144-288), homogeneous medium: the whole beam
+// BoundPhotonBeams (CastPhotons.h:144-288).  Homogeneous medium: the whole beam
 // becomes one segment, plus a second, ~1e-7-long one whenever the float length of
-// prior + dir*len - start falls short of len (:196-202).
+// prior + dir*len - start falls short of len (:196-202).  Heterogeneous medium: one
+// segment per interval between consecutive samples of Extinction3D along the beam,
+// carrying the extinction at both ends and the running mean up to it (:176-194, :270-277).
 template <bool WRITE>
 __global__ __launch_bounds__(256) void bound_kernel(const BoundParams p) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -338,7 +353,17 @@ __global__ __launch_bounds__(256) void bound_kernel(const BoundParams p) {
   const float theta_x = fminf(acosf(dot3(dir, x_dir)), acosf(dot3(dir, -x_dir)));
   const float theta_y = fminf(acosf(dot3(dir, y_dir)), acosf(dot3(dir, -y_dir)));
   const float theta_z = fminf(acosf(dot3(dir, z_dir)), acosf(dot3(dir, -z_dir)));
-  const float step = len;
+  float step = len;
+  const bool het = p.heterogeneous != 0;
+  DdaWalk walk;
+  float d_prev = 0.f, e_prev = 0.f, d_cur = 0.f, e_cur = 0.f;
+  float mean = p.extinction_c;
+  int current_step = 1;
+  if (het) {
+    walk.begin(p.grid, xyz(start), xyz(end));
+    walk.next(p.grid, d_prev, e_prev);
+    mean = e_prev;
+  }
   const bool ada = (b.flags & 1u) != 0;
   // BeamRadiance.h:449-455 always looks the energy up in beams_const[id]
   float en[3] = {0.f, 0.f, 0.f};
@@ -347,6 +372,11 @@ __global__ __launch_bounds__(256) void bound_kernel(const BoundParams p) {
   uint32_t count = 0;
   const uint32_t base = WRITE ? p.seg_offset[g] : 0u;
   while (j < len && len > 1e-6) {
+    if (het) {
+      if (!walk.next(p.grid, d_cur, e_cur)) break;   // cannot happen: the last sample ends the loop below
+      step = d_cur - d_prev;
+      mean = mean + ((e_cur - mean) / (current_step + 1));
+    }
     const V3 next = prior + (dir * step);
     const V3 s_start = prior;
     V3 s_end;
@@ -388,13 +418,18 @@ __global__ __launch_bounds__(256) void bound_kernel(const BoundParams p) {
       s.cull_lo[0] = mnx; s.cull_lo[1] = mny; s.cull_lo[2] = mxz;
       s.cull_hi[0] = mxx; s.cull_hi[1] = mxy; s.cull_hi[2] = mnz;
       s.energy[0] = en[0]; s.energy[1] = en[1]; s.energy[2] = en[2];
-      s.s_ext = 0.f; s.e_ext = 0.f; s.c_ext = p.extinction_c;
-      s.seg_id = 1; s.id = i;
+      s.s_ext = het ? e_prev : 0.f; s.e_ext = het ? e_cur : 0.f; s.c_ext = mean;
+      s.seg_id = current_step; s.id = i;
       s.flags = ada ? 1u : 0u;
       s.reserved[0] = s.reserved[1] = s.reserved[2] = 0u;
       p.segs[base + count] = s;
     }
     count++;
+    if (het) {
+      if (walk.state == 2) j = len + 1;   // that was the last sample (CastPhotons.h:273-275)
+      current_step++;
+      d_prev = d_cur; e_prev = e_cur;
+    }
   }
   if (!WRITE) p.seg_count[g] = count;
 }
@@ -436,7 +471,7 @@ struct TmpBuffers {
 }  // namespace
 
 int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
-  if (ctx->ctl.heterogeneous) { pb_set_error("pb_emit_beams: the heterogeneous medium is not implemented yet"); return PB_ERR_STATE; }
+  if (ctx->ctl.heterogeneous && !ctx->d_grid) { pb_set_error("pb_emit_beams: HETEROGENEOUS needs pb_set_grid first"); return PB_ERR_STATE; }
   hipStream_t s = ctx->stream;
   PB_HIP(hipEventRecord(ctx->ev[6], s));
   // scratch: cnt_const[n] cnt_scatt[n] off_const[n] off_scatt[n] totals[4] dropped[1] root[6] + scan tmp
@@ -459,6 +494,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
   ep.ctl = ctx->ctl; ep.seed = seed; ep.n_photons = n_photons;
   ep.cnt_const = cnt_const; ep.cnt_scatt = cnt_scatt; ep.off_const = off_const; ep.off_scatt = off_scatt;
   ep.dropped = totals + 3;
+  ep.grid.z = ctx->d_grid; ep.grid.side = ctx->grid_side;
   const int blocks = (n_photons + EMIT_THREADS - 1) / EMIT_THREADS;
   if (n_photons > 0) hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
   PB_HIP(hipGetLastError());
@@ -492,6 +528,8 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
   std::memset(&bp, 0, sizeof(bp));
   bp.beams = ctx->d_beams; bp.n_const = nc; bp.n_scatt = ns;
   bp.extinction_c = ctx->ctl.absorption_c + ctx->ctl.scattering_c;
+  bp.heterogeneous = ctx->ctl.heterogeneous ? 1 : 0;
+  bp.grid.z = ctx->d_grid; bp.grid.side = ctx->grid_side;
   bp.seg_count = seg_count; bp.seg_offset = seg_offset;
   if (nb > 0) hipLaunchKernelGGL(bound_kernel<false>, dim3((nb + 255) / 256), dim3(256), 0, s, bp);
   PB_HIP(hipGetLastError());

@@ -1,0 +1,119 @@
+// Extinction3D / FindAverageExtinction3D (Heterogeneous.h:29-185) on the device: the 3-D DDA through the
+// (side-1) x (side-1) x 2 cell grid over [-1,1] x [-1,1] x [2,4] and the bilinear look-up of sigma_t at
+// every cell crossing.  The reference collects the (distance, extinction) samples in a vector; here they
+// are produced one at a time by DdaWalk::next() and consumed on the fly, in the same order and with the
+// same float operations (translation units including this are built with -ffp-contract=off).
+//
+// The reference reads GRID.geometric_points out of bounds for samples whose cell index lies outside the
+// grid (rays that start in front of it); such indices are clamped into the array here.
+#ifndef PB_GRID_H
+#define PB_GRID_H
+#include "pb_device_math.h"
+
+struct GridView {
+  const float* z;   // GRID.geometric_points[i].z, i = row * side + column
+  int side;         // GRID.side_points
+};
+
+struct DdaWalk {
+  V3 o, dir, cell, delta, idx, prev;
+  float tx, ty, tz, t_max, res_x, res_y;
+  int state;        // 0: the sample at distance 0 is pending, 1: stepping, 2: finished
+  int guard;
+
+  PB_DI static void axis_setup(float d, float og, float c, float& delta, float& t) {
+    if (d < 0) { delta = -c / d; t = (floorf(og / c) * c - og) / d; }
+    else       { delta = c / d;  t = ((floorf(og / c) + 1) * c - og) / d; }
+  }
+
+  // Heterogeneous.h:34-79
+  PB_DI void begin(const GridView& g, V3 start, V3 end) {
+    const V3 grid_min = v3(-1, -1, 2);
+    const V3 d = end - start;
+    dir = normalize3(d);
+    res_x = (float)(g.side - 1); res_y = (float)(g.side - 1);
+    cell = v3(2.0f / res_x, 2.0f / res_y, 2.0f / 2.0f);
+    o = start - grid_min;
+    t_max = length3(d);
+    axis_setup(dir.x, o.x, cell.x, delta.x, tx);
+    axis_setup(dir.y, o.y, cell.y, delta.y, ty);
+    axis_setup(dir.z, o.z, cell.z, delta.z, tz);
+    idx = v3(floorf(o.x / cell.x), floorf(o.y / cell.y), floorf(o.z / cell.z));
+    prev = idx;
+    state = 0;
+    guard = 0;
+  }
+
+  // Heterogeneous.h:144-180 for one sample
+  PB_DI float sample(const GridView& g, float dist, V3 index) const {
+    const V3 p = o + (dir * dist);
+    const V3 mn = v3(cell.x * index.x, cell.y * index.y, cell.z * index.z);
+    const V3 dl = p - mn;
+    const float prop_x = fabsf(dl.x) / cell.x, prop_y = fabsf(dl.y) / cell.y;
+    const int side = g.side, last = side * side - 1;
+    int t_l = (int)((index.y * side) + index.x);
+    int b_l = (int)(((index.y + 1) * side) + index.x);
+    if (index.y + 1 >= side) b_l = t_l;
+    int t_r = t_l + 1;
+    if (index.x + 1 >= side) t_r = t_l;
+    const int b_r = b_l;                       // Heterogeneous.h:158: the unbraced `b_r = b_l` always runs
+    t_l = min(max(t_l, 0), last); b_l = min(max(b_l, 0), last); t_r = min(max(t_r, 0), last);
+    const float tl = g.z[t_l], bl = g.z[b_l], tr = g.z[t_r], br = g.z[min(max(b_r, 0), last)];
+    const float left = tl + ((bl - tl) * prop_y);
+    const float right = tr + ((br - tr) * prop_y);
+    float ext = left + ((right - left) * prop_x);
+    if (ext < 0) ext = 0;
+    return ext;
+  }
+
+  // Next (distance, extinction) sample; false once the list is exhausted.  Heterogeneous.h:84-122
+  PB_DI bool next(const GridView& g, float& dist, float& ext) {
+    if (state == 2) return false;
+    if (state == 0) {
+      state = 1;
+      dist = 0.0f;
+      ext = sample(g, 0.0f, idx);
+      return true;
+    }
+    float t;
+    if ((tx < ty) && (tx < tz)) { t = tx; tx += delta.x; idx.x += (dir.x < 0) ? -1.0f : 1.0f; }
+    else if (ty < tz)           { t = ty; ty += delta.y; idx.y += (dir.y < 0) ? -1.0f : 1.0f; }
+    else                        { t = tz; tz += delta.z; idx.z += (dir.z < 0) ? -1.0f : 1.0f; }
+    // a NaN direction (zero-length ray) never satisfies t > t_max: the guard ends such a walk
+    if (t > t_max || idx.x < 0 || idx.y < 0 || idx.x > res_x || idx.y > res_y || ++guard > 4096) {
+      state = 2;
+      dist = t_max;
+      ext = sample(g, t_max, prev);
+      return true;
+    }
+    prev = idx;
+    dist = t;
+    ext = sample(g, t, idx);
+    return true;
+  }
+};
+
+// Return value of Extinction3D: the plain mean of all samples (Heterogeneous.h:182-184).
+PB_DI float extinction3d_mean(const GridView& g, V3 start, V3 end) {
+  DdaWalk w;
+  w.begin(g, start, end);
+  float sum = 0.0f, d, e;
+  int n = 0;
+  while (w.next(g, d, e)) { sum += e; n++; }
+  return sum / (float)n;
+}
+
+// Running mean of the samples that lie before distance t_s (CastPhotons.h:437-443, :530-536).
+PB_DI float extinction3d_mean_until(const GridView& g, V3 start, V3 end, float t_s) {
+  DdaWalk w;
+  w.begin(g, start, end);
+  float mean = 0.0f, step = 0.0f, d, e;
+  while (w.next(g, d, e)) {
+    if (!(d < t_s)) break;
+    mean = mean + ((e - mean) / (step + 1));
+    step += 1.0f;
+  }
+  return mean;
+}
+
+#endif

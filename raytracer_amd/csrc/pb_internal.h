@@ -52,6 +52,17 @@ struct __attribute__((aligned(64))) SegFrame {
 };
 static_assert(sizeof(SegFrame) == 192, "SegFrame layout");
 
+// What Integral_73Het (BeamRadiance.h:211-288) reads of a segment beyond its end points: 8 dwords.
+struct __attribute__((aligned(32))) HetFrame {
+  float os[3];     // PhotonSeg.orig_start
+  float s_ext;     // extinction at the segment's start / end sample (CastPhotons.h:271-272)
+  float e_ext;
+  float c_ext;     // running mean up to the segment (CastPhotons.h:190-194)
+  int seg_id;      // 1-based index of the segment in its beam (CastPhotons.h:195)
+  float radius;
+};
+static_assert(sizeof(HetFrame) == 32, "HetFrame layout");
+
 // LBVH internal node as the tile traversal reads it: both child boxes inline, 64 B.
 // child >= 0: internal node index; child < 0: leaf, ~child = position in Morton order.
 struct __attribute__((aligned(64))) LbvhNode {
@@ -78,6 +89,10 @@ struct RenderParams {
   int width, height, ssaa; // SCREEN_WIDTH, SCREEN_HEIGHT, SSAA
   float focal;             // rasteriser.h:17
   float extinction_c;      // Control.h:48
+  float scattering_c;      // Control.h:47
+  const HetFrame* het;     // per segment, mode 73 only
+  const float* grid_z;     // sigma_t field (side*side) or nullptr
+  int grid_side;
   // geometry of this launch: tile (tx, k) covers pixels x = x0 + 8*tx + lx,
   // y = y0 + 8*k*strip_stride + ly; output row = 8*k + ly, row length out_w
   int x0, y0, out_w, out_h, strip_stride, tiles_x, tiles_y;
@@ -120,7 +135,8 @@ constexpr int PB_STACK_CAP = 2048;
 // (9e-13) by adding PB_FIX_MAGIC = 1.5 * 2^12 in double, and summed as 64-bit integers, so the sum does
 // not depend on the order in which candidates are met.  Valid for |contribution| < 2048.
 #define PB_FIX_MAGIC 6144.0
-#define PB_FIX_SCALE 9.094947017729282e-13   /* 2^-40 */     // LBVH traversal stack entries per wave (plus 128 of slack) // one resident wave slot per SIMD lane group of the chip
+#define PB_FIX_SCALE 9.094947017729282e-13   /* 2^-40 */
+#define PB_FIX_LIMIT 2047.0                   /* larger contributions saturate here (display range is [0,1]) */
 
 enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_SHORTCUT_WRONG, PB_CNT_N };
 
@@ -147,6 +163,10 @@ struct pb_ctx {
   SegFrame* d_frames = nullptr;
   float4* d_capA = nullptr;
   float4* d_capB = nullptr;
+  HetFrame* d_het = nullptr;
+  // extinction field of the heterogeneous medium
+  float* d_grid = nullptr;
+  int grid_side = 0;
   int n_seg = 0, cap_seg = 0, frame_mode = 0;
   bool have_segments = false;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
@@ -208,7 +228,7 @@ int pb_lbvh_download(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes
 // launchers implemented in the kernel translation units
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matrix16, TriPrep* d_out, hipStream_t s);
 int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float scattering_c, SegFrame* d_frames,
-                               float4* d_capA, float4* d_capB, hipStream_t s);
+                               float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s);
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);

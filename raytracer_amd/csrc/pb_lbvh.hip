@@ -25,7 +25,6 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 8;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
-constexpr int MORTON_BITS = 16;   // per axis
 constexpr int SORT_PASSES = 6;    // 48 bits / 8
 
 // order-preserving map float -> uint for atomicMin/atomicMax

@@ -69,7 +69,7 @@ __device__ void gate_setup(const float lo[3], const float hi[3], float cand[3], 
 
 __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int n, int mode, float scattering_c,
                                         SegFrame* __restrict__ frames, float4* __restrict__ capA,
-                                        float4* __restrict__ capB) {
+                                        float4* __restrict__ capB, HetFrame* __restrict__ het) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const pb_segment s = segs[i];
@@ -131,6 +131,11 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
   frames[i] = f;
   capA[i] = make_float4(start.x, start.y, start.z, s.radius);
   capB[i] = make_float4(end.x, end.y, end.z, 0.0f);
+  HetFrame h;
+  h.os[0] = ostart.x; h.os[1] = ostart.y; h.os[2] = ostart.z;
+  h.s_ext = s.s_ext; h.e_ext = s.e_ext; h.c_ext = s.c_ext;
+  h.seg_id = s.seg_id; h.radius = s.radius;
+  het[i] = h;
 }
 
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_matrix16, TriPrep* d_out, hipStream_t s) {
@@ -140,10 +145,10 @@ int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_ma
 }
 
 int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float scattering_c, SegFrame* d_frames,
-                               float4* d_capA, float4* d_capB, hipStream_t s) {
+                               float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s) {
   if (n <= 0) return PB_OK;
   hipLaunchKernelGGL(prepare_segments_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_segs, n, mode, scattering_c,
-                     d_frames, d_capA, d_capB);
+                     d_frames, d_capA, d_capB, d_het);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }

@@ -11,6 +11,7 @@
 // the reference's exact operation order.
 #include "pb_internal.h"
 #include "pb_geom.h"
+#include "pb_grid.h"
 
 namespace {
 
@@ -64,11 +65,16 @@ PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
   return r;
 }
 
-// HitCylinder (Intersections.h:307-456) with the per-segment frame prepared,
-// the two gates, Integral_721 (BeamRadiance.h:86-110) and the accumulation of
-// BeamRadianceStandard (BeamRadiance.h:441-455).  Returns 0 = no cylinder hit,
-// 1 = discriminant >= 0 but no contribution, 2 = contributed.
-PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, double& integral_out) {
+// CylIntersection (Intersections.h:29-40) of a valid hit.
+struct CylHit {
+  V3 entry, exit;
+  float tb_minus, tc_minus, tc_plus;
+};
+
+// HitCylinder (Intersections.h:307-456) with the per-segment frame prepared, then the segment's gate
+// box (BeamRadiance.h:426-430).  Returns 0 = no cylinder hit, 1 = discriminant >= 0 but nothing to
+// integrate, 2 = valid intersection behind an open gate (h filled in).
+PB_DI int hit_cylinder_exact(const SegFrame& f, const Ray& r, CylHit& h) {
   const V3 l = r.l;
   const float dpx = f.Rinv[0] * l.x + f.Rinv[3] * l.y + f.Rinv[6] * l.z;
   const float dpz = f.Rinv[2] * l.x + f.Rinv[5] * l.y + f.Rinv[8] * l.z;
@@ -126,14 +132,88 @@ PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, doubl
   const float qx = (f.R[0] * wx + f.R[3] * wy + f.R[6] * wz) / f.Sinv;
   const float qy = (f.R[1] * wx + f.R[4] * wy + f.R[7] * wz) / f.Sinv;
   const float qz = (f.R[2] * wx + f.R[5] * wy + f.R[8] * wz) / f.Sinv;
-  const float tc_minus = pb_sqrt(ex * ex + ey * ey + ez * ez);
-  const float tc_plus = pb_sqrt(qx * qx + qy * qy + qz * qz);
-  // Integral_721: float products and float exp, widened for the quotient
+  h.entry = v3(ex, ey, ez);
+  h.exit = v3(qx, qy, qz);
+  h.tb_minus = tb_minus;
+  h.tc_minus = pb_sqrt(ex * ex + ey * ey + ez * ez);
+  h.tc_plus = pb_sqrt(qx * qx + qy * qy + qz * qz);
+  return 2;
+}
+
+// Integral_721 (BeamRadiance.h:86-110) on a valid hit: float products and float exp, widened for the
+// quotient.  Same return convention as hit_cylinder_exact.
+PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, double& integral_out) {
+  CylHit h;
+  const int res = hit_cylinder_exact(f, r, h);
+  if (res != 2) return res;
+  const V3 l = r.l;
   const float cos_theta = f.bdir[0] * (-l.x) + f.bdir[1] * (-l.y) + f.bdir[2] * (-l.z);
   const float cm1 = fabsf(cos_theta) - 1;
-  const float num = expf(-extinction * (tc_minus - tc_plus) * cm1) - 1;
-  const float den = expf(extinction * (tc_minus + tb_minus)) * extinction * cm1;
+  const float num = expf(-extinction * (h.tc_minus - h.tc_plus) * cm1) - 1;
+  const float den = expf(extinction * (h.tc_minus + h.tb_minus)) * extinction * cm1;
   integral_out = (double)num / (double)den;
+  return 2;
+}
+
+// Integral_73Het (BeamRadiance.h:211-288): closest approach of the beam axis and the view ray in
+// double, the beam's extinction interpolated within the segment, the view ray's extinction by a
+// walk through the grid from the camera to the point of closest approach.
+struct D3v { double x, y, z; };
+PB_DI D3v d3(V3 v) { D3v r; r.x = (double)v.x; r.y = (double)v.y; r.z = (double)v.z; return r; }
+PB_DI D3v operator+(D3v a, D3v b) { D3v r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; return r; }
+PB_DI D3v operator-(D3v a, D3v b) { D3v r; r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z; return r; }
+PB_DI D3v operator*(double s, D3v a) { D3v r; r.x = s * a.x; r.y = s * a.y; r.z = s * a.z; return r; }
+PB_DI D3v operator*(D3v a, double s) { D3v r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; return r; }
+PB_DI double ddot(D3v a, D3v b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PB_DI double dlength(D3v a) { return __builtin_sqrt(ddot(a, a)); }
+PB_DI D3v dnormalize(D3v a) { return a * (1.0 / __builtin_sqrt(ddot(a, a))); }
+
+PB_DI double integral_73het(const GridView& grid, V3 seg_start, V3 seg_end, const HetFrame& hf, const CylHit& h,
+                            const Ray& r, float extinction_c, float scattering_c) {
+  const D3v a = d3(seg_start), c = d3(h.exit);
+  const D3v b = d3(seg_end), d = d3(h.entry);
+  const D3v ab = dnormalize(b - a);
+  const D3v cd = dnormalize(d - c);
+  const double u_dot_u = ddot(ab, ab), u_dot_v = ddot(ab, cd), v_dot_v = ddot(cd, cd);
+  const double u_dot_w = ddot(ab, a - c), v_dot_w = ddot(cd, a - c);
+  const double denominator = u_dot_u * v_dot_v - u_dot_v * u_dot_v;
+  if (!((denominator != 0) && (u_dot_u != 0) && (v_dot_v != 0))) return 0.0;
+  const double t_ab = (u_dot_v * v_dot_w - v_dot_v * u_dot_w) / denominator;
+  const double t_cd = (u_dot_u * v_dot_w - u_dot_v * u_dot_w) / denominator;
+  const D3v point_beam = a + (t_ab * ab);
+  const D3v point_view = c + (t_cd * cd);
+  const D3v os = d3(v3(hf.os[0], hf.os[1], hf.os[2]));
+  const double view_distance = dlength(point_view);
+  const double beam_distance = dlength(point_beam - os);
+  const double a_os = dlength(a - os), b_os = dlength(b - os);
+  const bool bound1 = (view_distance >= dlength(d)) && (view_distance <= dlength(c));
+  const bool bound2 = (beam_distance >= a_os) && (beam_distance <= b_os);
+  if (!(bound1 && bound2)) return 0.0;
+  const double t_bc = beam_distance;
+  const double t_cb = view_distance;
+  const float proportion = (float)((t_bc - a_os) / (b_os - a_os));
+  const float additional = hf.s_ext + ((hf.e_ext - hf.s_ext) * proportion);
+  const float beam_extinction = hf.c_ext + ((additional - hf.c_ext) / (hf.seg_id + 1));
+  // vec4(0,0,0,1) + dir * (float) t_cb, dir the normalised vec4 of DrawHet (skeleton.cpp:383-387)
+  const float reach = (float)t_cb;
+  const V3 view_end = v3(0.0f + (r.dn.x * reach), 0.0f + (r.dn.y * reach), 0.0f + (r.dn.z * reach));
+  const float view_extinction = extinction3d_mean(grid, v3(0, 0, 0), view_end);
+  const double transmitted = exp(-(double)beam_extinction * t_bc) * exp(-(double)view_extinction * t_cb);
+  const float scattering = (beam_extinction / extinction_c) * scattering_c;
+  if (transmitted < 1e-6) return 0.0;
+  const double cos_theta = ddot(ab, cd);
+  const double sin_theta = __builtin_sqrt(1 - cos_theta * cos_theta);
+  const double rad = (double)(scattering / hf.radius);
+  return transmitted * rad / sin_theta;
+}
+
+// One (ray, segment) pair of BVHBeamRadianceHet (BeamRadiance.h:378-398).
+PB_DI int eval_pair_73het(const SegFrame& f, const HetFrame& hf, V3 seg_start, V3 seg_end, const GridView& grid,
+                          const Ray& r, float extinction_c, float scattering_c, double& integral_out) {
+  CylHit h;
+  const int res = hit_cylinder_exact(f, r, h);
+  if (res != 2) return res;
+  integral_out = integral_73het(grid, seg_start, seg_end, hf, h, r, extinction_c, scattering_c);
   return 2;
 }
 
@@ -407,7 +487,24 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   }
 }
 
-template <bool COUNT, bool PRECISE>
+// Radiance weight times integral for one pair, by either estimator.
+template <bool COUNT, bool PRECISE, int MODE>
+PB_DI int eval_pair(const RenderParams& p, int sidx, const SegFrame& f, const Ray& r, double& integral,
+                    unsigned long long& c_wrong) {
+  if (MODE == PB_MODE_73HET) {
+    const HetFrame hf = pb_uniform(p.het)[sidx];
+    const PB_CONST_AS float* A = pb_uniform((const float*)p.capA) + 4 * (size_t)sidx;
+    const PB_CONST_AS float* B = pb_uniform((const float*)p.capB) + 4 * (size_t)sidx;
+    GridView grid;
+    grid.z = p.grid_z; grid.side = p.grid_side;
+    return eval_pair_73het(f, hf, v3(A[0], A[1], A[2]), v3(B[0], B[1], B[2]), grid, r, p.extinction_c, p.scattering_c,
+                           integral);
+  }
+  return PRECISE ? eval_pair_721(f, r, p.extinction_c, integral)
+                 : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, integral, c_wrong);
+}
+
+template <bool COUNT, bool PRECISE, int MODE>
 __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
   const int lane = threadIdx.x;
   unsigned long long c_cand = 0, c_cyl = 0, c_valid = 0, c_wrong = 0;
@@ -432,8 +529,7 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
       const int sidx = (int)ch[4 + k];
       const SegFrame f = pb_uniform(p.frames)[sidx];
       double integral = 0.0;
-      const int res = PRECISE ? eval_pair_721(f, r, p.extinction_c, integral)
-                              : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, integral, c_wrong);
+      const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong);
       if (res == 2) {
         // BeamRadiance.h:455: current += energy * phase_f * rad * _int, product and sum rounded separately
         acc[0] = acc[0] + f.W[0] * integral;
@@ -683,7 +779,7 @@ __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, i
   }
 }
 
-template <bool COUNT, bool PRECISE>
+template <bool COUNT, bool PRECISE, int MODE>
 __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
   __shared__ uint32_t surv[PB_SLICE];
   const int lane = threadIdx.x;
@@ -733,9 +829,12 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
       const int sidx = __builtin_amdgcn_readfirstlane((int)surv[k]);
       const SegFrame f = pb_uniform(p.frames)[sidx];
       double integral = 0.0;
-      const int res = PRECISE ? eval_pair_721(f, r, p.extinction_c, integral)
-                              : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, integral, c_wrong);
+      const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong);
       if (res == 2) {
+        if (MODE == PB_MODE_73HET) {
+          // 1/sin(theta) is unbounded for a beam seen end-on: saturate far above the display range
+          integral = fmin(integral, PB_FIX_LIMIT / fmax(f.W[0], fmax(f.W[1], f.W[2])));
+        }
         ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
         ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[1], integral, PB_FIX_MAGIC));
         ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[2], integral, PB_FIX_MAGIC));
@@ -791,15 +890,18 @@ int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
 }
 
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s) {
-  if (mode != PB_MODE_721) { pb_set_error("pb_render: only PB_MODE_721 is implemented"); return PB_ERR_ARG; }
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
   int waves = p.chunk_capacity < PB_EVAL_WAVES ? p.chunk_capacity : PB_EVAL_WAVES;
   if (waves < 1) waves = 1;
-  if (count && p.precise) hipLaunchKernelGGL((eval_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
-  else if (count) hipLaunchKernelGGL((eval_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
-  else if (p.precise) hipLaunchKernelGGL((eval_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL((eval_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
+  if (mode == PB_MODE_73HET) {
+    if (count) hipLaunchKernelGGL((eval_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((eval_kernel<false, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
+  }
+  else if (count && p.precise) hipLaunchKernelGGL((eval_kernel<true, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
+  else if (count) hipLaunchKernelGGL((eval_kernel<true, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
+  else if (p.precise) hipLaunchKernelGGL((eval_kernel<false, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL((eval_kernel<false, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   hipLaunchKernelGGL(reduce_kernel, dim3(tiles), dim3(64), 0, s, p);
   PB_HIP(hipGetLastError());
   return PB_OK;
@@ -826,17 +928,20 @@ int pb_launch_bin_count(const RenderParams& p, hipStream_t s) {
 }
 
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s) {
-  if (mode != PB_MODE_721) { pb_set_error("pb_render: only PB_MODE_721 is implemented"); return PB_ERR_ARG; }
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
   if (p.n_seg > 0) hipLaunchKernelGGL(bin_kernel<true>, dim3((p.n_seg + 255) / 256), dim3(256), 0, s, p);
   hipLaunchKernelGGL(make_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
   int waves = p.item_capacity < PB_EVAL_WAVES ? p.item_capacity : PB_EVAL_WAVES;
   if (waves < 1) waves = 1;
-  if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
-  else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
-  else if (p.precise) hipLaunchKernelGGL((eval_bins_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL((eval_bins_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
+  if (mode == PB_MODE_73HET) {
+    if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
+  }
+  else if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
+  else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
+  else if (p.precise) hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL((eval_bins_kernel<false, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   const size_t px = (size_t)p.out_w * p.out_h;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, p);
   PB_HIP(hipGetLastError());

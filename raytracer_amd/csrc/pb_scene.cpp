@@ -63,3 +63,81 @@ extern "C" int pb_load_test_model(float* tri_xyz, float* normals_xyz, int capaci
   }
   return n;
 }
+
+// ----------------------------------------------------------------------------------------------
+// Extinction field of the heterogeneous medium.
+//
+// CreateSurface + UpdateHeight (Tessendorf.h:47-132) lay a (triangle_number+1)^2 lattice over
+// [-1,1]^2 and set z = |sum over a 5x5 block of wave vectors of h(k,t) * exp(i k.x)| + height.  The
+// spectrum term h(k,t) = sqrt(P(k)/2) xi e^{i w t} + sqrt(P(-k)/2) xi e^{-i w t} does not depend on
+// the lattice point, so it is tabulated once per wave vector; the per-point sum then runs over the
+// table in the reference's (n, m) loop order with the same float operations.
+// ----------------------------------------------------------------------------------------------
+#include <complex>
+#include <vector>
+
+extern "C" int pb_create_surface(int triangle_number, float height, double time, float* points_xyzw, int capacity_points) {
+  if (triangle_number < 1 || !points_xyzw) return PB_ERR_ARG;
+  typedef std::complex<float> cf;
+  const float width = 2.0f, half = width / 2;                        // ACTUAL_WIDTH, HALF_W  :23-24
+  const float gravity = 9.8f, max_wave = 0.4f, amplitude = 0.2f;     // :31-34
+  const float wind[2] = {0.424f, 0.316f};
+  const float dk = half / 5;                                         // `step`  :36
+  const double xi_re = 0.5, xi_im = 0.5;                             // e_r, e_i  :40-41
+  const double pi = 3.14159265;                                      // :4
+  const int side = triangle_number + 1;
+  const int total = side * side;
+  if (capacity_points < total) return PB_ERR_CAPACITY;
+
+  struct Wave { float kx, kz; cf h; };
+  std::vector<Wave> table;
+  const float inv_sqrt2 = (float)(1 / std::sqrt(2.0));               // `multiplier`  :83
+  for (float n = 0; n < half; n = n + dk) {                          // float counters decide the wave count
+    for (float m = 0; m < half; m = m + dk) {
+      Wave wv;
+      wv.kx = (float)((2 * pi * (n - half / 2)) / max_wave);
+      wv.kz = (float)((2 * pi * (m - half / 2)) / max_wave);
+      const float k2 = wv.kx * wv.kx + wv.kz * wv.kz;
+      const float k_len = std::sqrt(k2);
+      const float omega = std::sqrt(gravity * k_len);
+      const float k_len4 = (float)std::pow((double)k_len, 4);
+      const cf backward((float)std::cos(-time * omega), (float)std::sin(-time * omega));
+      const cf forward((float)std::cos(time * omega), (float)std::sin(time * omega));
+      float p_plus = 0, p_minus = 0;                                 // Phillips spectrum for k and -k
+      if (k_len4 != 0) {
+        const float along = wv.kx * wind[0] + wv.kz * wind[1];
+        const float against = (-wv.kx) * wind[0] + (-wv.kz) * wind[1];
+        p_plus = (float)(amplitude * (std::exp(-1 / k2) / k_len4) * std::pow((double)std::fabs(along), 2));
+        p_minus = (float)(amplitude * (std::exp(-1 / k2) / k_len4) * std::pow((double)std::fabs(against), 2));
+      }
+      const cf xi((float)xi_re, (float)xi_im);
+      const cf a = inv_sqrt2 * xi * cf(std::sqrt(p_plus));
+      const cf b = inv_sqrt2 * xi * cf(std::sqrt(p_minus));
+      wv.h = (a * forward) + (b * backward);
+      table.push_back(wv);
+    }
+  }
+  const float pitch = width / (float)triangle_number;
+  for (int i = 0; i < total; ++i) {
+    // lattice point, shifted by (HALF_W, HALF_W)  :57-66
+    const float x = (i % side) * pitch - half;
+    const float y = (float)std::floor((double)(i / side)) * pitch - half;
+    cf sum = 0;
+    for (const Wave& wv : table) {
+      const float phase = wv.kx * x + wv.kz * y;
+      sum += wv.h * cf(std::cos(phase), std::sin(phase));
+    }
+    float z = std::abs(sum);
+    z += height;
+    points_xyzw[i * 4 + 0] = x; points_xyzw[i * 4 + 1] = y; points_xyzw[i * 4 + 2] = z; points_xyzw[i * 4 + 3] = 1.0f;
+  }
+  return total;
+}
+
+extern "C" void pb_transform_points(const float M[16], float* p, int n) {
+  for (int i = 0; i < n; ++i) {
+    const float x = p[i * 4], y = p[i * 4 + 1], z = p[i * 4 + 2], w = p[i * 4 + 3];
+    // glm mat4 * vec4: (col0*x + col1*y) + (col2*z + col3*w)   type_mat4x4.inl:641-652
+    for (int r = 0; r < 4; ++r) p[i * 4 + r] = (M[r] * x + M[4 + r] * y) + (M[8 + r] * z + M[12 + r] * w);
+  }
+}
