@@ -12,6 +12,7 @@ broadcast before timing.  Rank 0 prints one JSON line.
 Workloads (BASELINE.json `configs`):
   cfg1  512^2,  1000 photons, BOUNCES 0          (the reference's own CPU case)
   cfg2  512^2, 10000 photons, BOUNCES 3          (default: the metric's 512^2 configuration)
+  cfg3  512^2, 10000 photons, BOUNCES 3, heterogeneous medium (Integral_73Het estimator)
   cfg4  1024^2, 100000 photons, BOUNCES 0
 """
 import argparse
@@ -28,6 +29,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     "cfg1": dict(screen_width=512, screen_height=512, photon_number=1000, bounces=0),
     "cfg2": dict(screen_width=512, screen_height=512, photon_number=10000, bounces=3),
+    "cfg3": dict(screen_width=512, screen_height=512, photon_number=10000, bounces=3, heterogeneous=1, one_dimensional=1),
     "cfg4": dict(screen_width=1024, screen_height=1024, photon_number=100000, bounces=0),
 }
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 peak (packed issue), MI355X_MICROARCH.md chip table
@@ -39,7 +41,7 @@ def flop_per_ray(n_cull, n_valid):
     return 900.0 + 46.0 * n_cull + 67.0 * n_valid
 
 
-def cpu_baseline(args, control_kwargs, segs, root_lo, root_hi):
+def cpu_baseline(args, control_kwargs, segs, root_lo, root_hi, grid=None):
     """The CPU restatement (oracle/, test infrastructure) of the same estimate on a bounded pixel
     lattice of the same frame, on this host's cores.  Reported beside the GPU number, never part of it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -48,15 +50,17 @@ def cpu_baseline(args, control_kwargs, segs, root_lo, root_hi):
     tri, _ = orc.load_test_model()
     threads = min(orc.max_threads(), 16)
     w, h = control_kwargs["screen_width"], control_kwargs["screen_height"]
-    # aim for ~10-20 s: the flat scan costs about 60 ns per (ray, segment) pair and core
-    rays_budget = 15.0 * threads / (60e-9 * max(len(segs), 1))
+    # aim for ~10-20 s: the flat scan costs about 15 ns per (ray, segment) pair and core (box gates reject most)
+    rays_budget = 15.0 * threads / (15e-9 * max(len(segs), 1))
     step = 1
     while (w // step) * (h // step) > rays_budget and step < 64:
         step *= 2
     nx, ny = w // step, h // step
     t0 = time.perf_counter()
     _, cnt = orc.render_segments(ctl, orc.tri_xyz(tri), orc.transformation_matrix(), segs, root_lo, root_hi,
-                                 step // 2, step // 2, nx, ny, step_x=step, step_y=step, threads=threads)
+                                 step // 2, step // 2, nx, ny, step_x=step, step_y=step, threads=threads,
+                                 mode=orc.MODE_73HET if grid is not None else orc.MODE_721,
+                                 grid_sigma=None if grid is None else grid[0], side=0 if grid is None else grid[1])
     dt = time.perf_counter() - t0
     return {"value": cnt["rays"] / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
             "sample": f"every {step}th pixel in x and y of the same frame ({nx}x{ny} rays, {dt:.1f} s), "
@@ -103,6 +107,11 @@ def main():
     W, H = wk["screen_width"], wk["screen_height"]
     ctx = pb.Context(ctl, device=local_rank)
     ctx.set_scene()
+    het = bool(wk.get("heterogeneous"))
+    mode = pb.MODE_73HET if het else pb.MODE_721
+    grid = pb.make_grid() if het else None
+    if het:
+        ctx.set_grid(*grid)      # CreateSurface(27, -3.0, 0.016) moved into camera space (skeleton.cpp:113-125)
 
     # ---- beam set: emitted once on rank 0 (GPU photon pass), broadcast, resident everywhere ----
     if rank == 0:
@@ -135,7 +144,7 @@ def main():
     def step(i=None):
         if i is not None:
             ev0[i].record()
-        ctx.draw_strips_device(mine.data_ptr(), first_strip, strip_stride, n_my, cull=cull, stream=stream)
+        ctx.draw_strips_device(mine.data_ptr(), first_strip, strip_stride, n_my, mode=mode, cull=cull, stream=stream)
         if i is not None:
             ev1[i].record()
         tiles.gather_frame(mine, gathered, frame, world)     # RCCL all-gather of the row tiles + reorder
@@ -170,7 +179,7 @@ def main():
         # algorithmic work per ray from the counters of one counted frame (not timed)
         ctx.enable_counters(True)
         full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-        ctx.draw_device(full.data_ptr(), 0, 0, W, H, cull=cull, stream=stream)
+        ctx.draw_device(full.data_ptr(), 0, 0, W, H, mode=mode, cull=cull, stream=stream)
         torch.cuda.synchronize()
         cnt = ctx.counters()
         ctx.enable_counters(False)
@@ -186,7 +195,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: Cornell box {W}x{H}, {wk['photon_number']} photons, "
-                                   f"BOUNCES {wk['bounces']}, homogeneous medium, SEED 42 (GPU photon pass: "
+                                   f"BOUNCES {wk['bounces']}, {'heterogeneous' if het else 'homogeneous'} medium, SEED 42 (GPU photon pass: "
                                    f"{n_beams} beams, {n_segs} segments, own-box gate rule)",
                        "rays_per_frame": rays, "segments": n_segs, "cull": cull,
                        "parallelism": f"row-strips x{world}" if world > 1 else "single GPU"},
@@ -201,7 +210,7 @@ def main():
             "phases_ms": {k: cnt[k] for k in ("ms_emit", "ms_prepare", "ms_build")},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, wk, segs, root[:3], root[3:])
+            out["cpu_baseline"] = cpu_baseline(args, wk, segs, root[:3], root[3:], grid)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

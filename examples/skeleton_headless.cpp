@@ -1,6 +1,7 @@
-// StandardRun of the reference (skeleton.cpp:205-233) written against raytracer_amd/host/photon_beams_host.h:
-// the same calls in the same order, one frame, screenshot.bmp written headless.
-//   ./skeleton_headless [photons] [bounces] [width] [out.bmp]
+// StandardRun (skeleton.cpp:205-233) and HeterogeneousRun (skeleton.cpp:111-203) of the reference written
+// against raytracer_amd/host/photon_beams_host.h: the same calls in the same order, one frame,
+// screenshot.bmp written headless.
+//   ./skeleton_headless [photons] [bounces] [width] [out.bmp] [het]
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
@@ -15,11 +16,26 @@ int main(int argc, char** argv) {
   if (argc > 2) control.bounces = std::atoi(argv[2]);
   if (argc > 3) control.screen_width = control.screen_height = std::atoi(argv[3]);
   const char* out = argc > 4 ? argv[4] : "screenshot.bmp";
+  const bool het = argc > 5 && std::atoi(argv[5]) != 0;
+  control.heterogeneous = het ? 1 : 0;      // Control.h: HETEROGENEOUS, ONE_DIMENSIONAL
+  control.one_dimensional = het ? 1 : 0;
   try {
     std::vector<Triangle> triangles;
     LoadTestModel(triangles);
     mat4 matrix;
     TransformationMatrix(matrix);
+    if (het) {
+      std::cout << "Creating grid" << std::endl;
+      CreateSurface(27, -3.0, 0.016);
+      float minimum = 10, maximum = -10;
+      for (size_t i = 0; i < GRID.geometric_points.size(); i++) {
+        pb_transform_points(&matrix.m[0][0], &GRID.geometric_points[i].x, 1);
+        if (GRID.geometric_points[i].z < minimum) minimum = GRID.geometric_points[i].z;
+        if (GRID.geometric_points[i].z > maximum) maximum = GRID.geometric_points[i].z;
+      }
+      std::cout << "Minimum value: " << minimum << std::endl;
+      std::cout << "Maximum value: " << maximum << std::endl;
+    }
     std::vector<PhotonBeam> beams_const, beams_scatt;
     std::vector<PhotonSeg> items;
     std::cout << "Casting photons" << std::endl;
@@ -34,7 +50,8 @@ int main(int argc, char** argv) {
     std::cout << "Calculating radiance" << std::endl;
     screen* scr = InitializeSDL(control.screen_width, control.screen_height, false);
     auto t0 = std::chrono::steady_clock::now();
-    DrawStandard(scr, beams_const, beams_scatt);
+    if (het) DrawHet(scr, beams_const, beams_scatt, nullptr);
+    else DrawStandard(scr, beams_const, beams_scatt);
     SDL_Renderframe(scr);
     auto t1 = std::chrono::steady_clock::now();
     std::cout << "Render time: " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms." << std::endl;

@@ -16,6 +16,7 @@ float scattering_c = (float)0.005;
 float extinction_c = absorption_c + scattering_c;
 vec4 camera{0, 0, -3, 1.0f};
 vec3 theta{0.0f, 0.0f, 0.0f};
+Grid GRID;
 pb_control control = [] { pb_control c; pb_control_defaults(&c); return c; }();
 
 namespace {
@@ -56,6 +57,14 @@ void recreate_context_if_control_changed() {
 
 vec4 v4(const float* p) { return vec4{p[0], p[1], p[2], p[3]}; }
 
+void upload_grid(pb_ctx* ctx, const Grid& grid) {
+  if (grid.side_points < 2 || (int)grid.geometric_points.size() != grid.side_points * grid.side_points)
+    throw std::runtime_error("GRID is empty: call CreateSurface before a HETEROGENEOUS photon pass");
+  std::vector<float> sigma(grid.geometric_points.size());
+  for (size_t i = 0; i < sigma.size(); ++i) sigma[i] = grid.geometric_points[i].z;
+  check(pb_set_grid(ctx, sigma.data(), grid.side_points), "pb_set_grid");
+}
+
 }  // namespace
 
 void LoadTestModel(std::vector<Triangle>& triangles) {
@@ -94,6 +103,7 @@ AABB CastPhotonBeams(int number, std::vector<PhotonBeam>& beams_const, std::vect
   }
   g_triangles = triangles;
   check(pb_set_scene(ctx, tri.data(), (int)triangles.size(), &matrix.m[0][0]), "pb_set_scene");
+  if (control.heterogeneous) upload_grid(ctx, GRID);
   int n_beams = 0, n_segs = 0;
   check(pb_emit_beams(ctx, number, control.seed, &n_beams, &n_segs), "pb_emit_beams");
   check(pb_beam_counts(ctx, &g_n_const, &g_n_scatt), "pb_beam_counts");
@@ -175,6 +185,30 @@ void BuildTree(Node* parent, std::vector<PhotonSeg>& child, int) {
   parent->leaf = child.size() <= 2;
 }
 
+void CreateSurface(int triangle_number, float height, double time) {
+  const int side = triangle_number + 1;
+  std::vector<float> pts((size_t)side * side * 4);
+  const int n = pb_create_surface(triangle_number, height, time, pts.data(), side * side);
+  if (n != side * side) throw std::runtime_error("pb_create_surface failed");
+  GRID.height = height;
+  GRID.side_points = side;
+  GRID.geometric_points.resize((size_t)n);
+  for (int i = 0; i < n; ++i) GRID.geometric_points[(size_t)i] = v4(&pts[(size_t)i * 4]);
+}
+
+float Extinction3D(const vec4 start, const vec4 end, const Grid grid, std::vector<vec2>& dist_ext) {
+  pb_ctx* ctx = context();
+  upload_grid(ctx, grid);
+  const float a[3] = {start.x, start.y, start.z}, b[3] = {end.x, end.y, end.z};
+  const int cap = 4 * grid.side_points + 16;   // at most one sample per cell face crossed, plus the two ends
+  std::vector<float> samples((size_t)cap * 2);
+  float mean = 0.0f;
+  int count = 0;
+  check(pb_extinction3d(ctx, a, b, 1, &mean, &count, samples.data(), cap), "pb_extinction3d");
+  for (int i = 0; i < count && i < cap; ++i) dist_ext.push_back(vec2{samples[(size_t)i * 2], samples[(size_t)i * 2 + 1]});
+  return mean;
+}
+
 screen* InitializeSDL(int width, int height, bool) {
   screen* s = new screen;
   s->width = width; s->height = height;
@@ -220,6 +254,13 @@ void DrawStandard(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>)
   pb_ctx* ctx = context();
   std::vector<float> rgb((size_t)scr->width * scr->height * 3);
   check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_721, /*screen bins*/ 2, rgb.data()), "pb_render");
+  check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
+}
+
+void DrawHet(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, NodeGen*) {
+  pb_ctx* ctx = context();
+  std::vector<float> rgb((size_t)scr->width * scr->height * 3);
+  check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_73HET, /*screen bins*/ 2, rgb.data()), "pb_render");
   check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
 }
 

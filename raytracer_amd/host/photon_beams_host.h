@@ -53,6 +53,10 @@ struct PhotonBeam {                                                             
 };
 struct Node { AABB aabb; bool leaf; };   // CastPhotons.h:49-56: handle only, the hierarchy lives on the GPU
 struct screen { int height, width; uint32_t* buffer; };                          // SDLauxiliary.h:9-16
+struct vec2 { float x, y; };
+struct Grid { float height; int side_points; std::vector<vec4> geometric_points; };   // Tessendorf.h:16-21
+struct NodeGen;                                                                  // CastPhotons.h:40-47: never dereferenced
+extern Grid GRID;                                                                // Tessendorf.h:27
 
 void LoadTestModel(std::vector<Triangle>& triangles);                            // TestModelH.h:45
 void TransformationMatrix(mat4& M);                                              // skeleton.cpp:512
@@ -67,6 +71,13 @@ Node* newNode(AABB data);                                                       
 // BeamRadiance.h:449-455 does) and builds the acceleration structure over it.
 void BuildTree(Node* parent, std::vector<PhotonSeg>& child, int leftover);           // CastPhotons.h:105
 
+// Tessendorf.h:47-75: fills GRID (host arithmetic, pb_create_surface).  HeterogeneousRun then multiplies
+// every GRID point by the camera matrix itself (skeleton.cpp:119-125); CastPhotonBeams hands GRID's z
+// values to the GPU when control.heterogeneous is set.
+void CreateSurface(int triangle_number, float height, double time);
+// Heterogeneous.h:29-135 for one ray (GPU; use pb_extinction3d directly for batches).
+float Extinction3D(const vec4 start, const vec4 end, const Grid grid, std::vector<vec2>& dist_ext);
+
 screen* InitializeSDL(int width, int height, bool fullscreen = false);               // SDLauxiliary.h:72
 void PutPixelSDL(screen* s, int x, int y, vec3 colour);                              // SDLauxiliary.h:149
 void SDL_Renderframe(screen* s);                                                     // SDLauxiliary.h:64
@@ -76,6 +87,10 @@ void KillSDL(screen* s);                                                        
 // One frame of skeleton.cpp:330-365 on the GPU; uses the tree of the last BuildTree as the reference
 // uses its global `root`.
 void DrawStandard(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scatt);
+
+// One frame of skeleton.cpp:367-412 (BVHBeamRadianceHet with Integral_73Het); the NodeGen argument is
+// unused there as well.
+void DrawHet(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scattered, NodeGen*);
 
 // Counters and device times of the last calls (pb_counters).
 pb_stats Stats();

@@ -43,3 +43,23 @@ def test_standard_run_through_reference_named_functions(tmp_path):
     assert f"Beams size: {n_beams}" in r.stdout and f"Segment size: {n_segs}" in r.stdout
     assert np.array_equal(img, ref)
     assert (img & 0xFF).max() > 100
+
+
+def test_heterogeneous_run_through_reference_named_functions(tmp_path):
+    """HeterogeneousRun: CreateSurface, GRID moved by the caller, CastPhotonBeams, DrawHet."""
+    import raytracer_amd as pb
+    out = str(tmp_path / "het.bmp")
+    r = subprocess.run([EXE, "800", "1", "128", out, "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert "Creating grid" in r.stdout and "Minimum value:" in r.stdout
+    img = read_bmp32(out)
+    kw = dict(photon_number=800, bounces=1, screen_width=128, screen_height=128, heterogeneous=1, one_dimensional=1)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.set_grid(*pb.make_grid())
+        n_beams, n_segs = ctx.cast_photon_beams()
+        ref = pb.quantise_argb(ctx.draw(mode=pb.MODE_73HET, cull="bins"))
+    assert f"Beams size: {n_beams}" in r.stdout and f"Segment size: {n_segs}" in r.stdout
+    assert np.array_equal(img, ref)
+    assert (img & 0xFF).max() > 20
