@@ -207,6 +207,7 @@ def main():
                                  "flop per ray x rays per launch / measured launch time"},
             "pair_queries_per_s": rays * n_segs * args.steps / dt,
             "frame_ok": frame_ok,
+            "per_ray": {k: cnt[k] / rays for k in ("candidates", "cyl_hits", "valid_hits", "gate_passes")},
             "phases_ms": {k: cnt[k] for k in ("ms_emit", "ms_prepare", "ms_build")},
         }
         if not args.no_cpu_baseline and world == 1:

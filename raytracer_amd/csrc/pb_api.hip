@@ -2,6 +2,8 @@
 // include/photon_beams.h).  Host code here only moves data, launches kernels and
 // keeps the context; nothing of the radiance path runs on the CPU.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -102,7 +104,7 @@ int ensure_bin_workspace(pb_ctx* ctx, int tiles, int bin_cap, int item_cap, size
     if (ctx->d_tile_u32) PB_HIP(hipFree(ctx->d_tile_u32));
     if (ctx->d_scan_tmp) PB_HIP(hipFree(ctx->d_scan_tmp));
     ctx->d_tile_u32 = nullptr; ctx->d_scan_tmp = nullptr; ctx->ws_tiles = 0;
-    PB_HIP(hipMalloc(&ctx->d_tile_u32, sizeof(uint32_t) * (2 + 3 * (size_t)PB_BIN_SUBS) * (size_t)tiles));   // macro tiles <= tiles
+    PB_HIP(hipMalloc(&ctx->d_tile_u32, sizeof(uint32_t) * (4 + 3 * (size_t)PB_BIN_SUBS) * (size_t)tiles));   // macro tiles <= tiles
     PB_HIP(hipMalloc(&ctx->d_scan_tmp, sizeof(uint32_t) * pb_scan_tmp_words(tiles * PB_BIN_SUBS)));
     ctx->ws_tiles = tiles;
   }
@@ -141,15 +143,18 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
   for (int attempt = 0; attempt < 4; ++attempt) {
     int rc = ensure_workspace(ctx, groups, 0);
     if (rc != PB_OK) return rc;
-    rc = ensure_bin_workspace(ctx, tiles, want_bins, want_items, px);
+    const int mtiles = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
+    const int slots = mtiles * PB_MACRO * PB_MACRO;     // queue slots: every macro tile has room for all its tiles
+    rc = ensure_bin_workspace(ctx, slots, want_bins, want_items, px);
     if (rc != PB_OK) return rc;
     p.rays = ctx->d_rays; p.group_last = ctx->d_group_last; p.ctrl = ctx->d_ctrl;
-    const int mtiles = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
     {
       const size_t T = (size_t)ctx->ws_tiles;
       p.tile_count = ctx->d_tile_u32; p.item_off = ctx->d_tile_u32 + T;
-      p.sub_count = ctx->d_tile_u32 + 2 * T; p.sub_fill = p.sub_count + T * PB_BIN_SUBS; p.sub_off = p.sub_fill + T * PB_BIN_SUBS;
+      p.macro_cnt = ctx->d_tile_u32 + 2 * T; p.macro_rank = ctx->d_tile_u32 + 3 * T;
+      p.sub_count = ctx->d_tile_u32 + 4 * T; p.sub_fill = p.sub_count + T * PB_BIN_SUBS; p.sub_off = p.sub_fill + T * PB_BIN_SUBS;
     }
+    PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
     p.bin_list = ctx->d_bin_list; p.items = ctx->d_items; p.accum = ctx->d_accum;
     p.bin_capacity = ctx->ws_bin_cap; p.item_capacity = ctx->ws_item_cap;
     PB_HIP(hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * 4, s));
@@ -162,13 +167,14 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
     if (rc != PB_OK) return rc;
     rc = pb_exclusive_scan_u32(p.sub_count, p.sub_off, mtiles * PB_BIN_SUBS, ctx->d_ctrl + 2, ctx->d_scan_tmp, s);
     if (rc != PB_OK) return rc;
-    rc = pb_exclusive_scan_u32(p.item_off, p.item_off, tiles, ctx->d_ctrl + 0, ctx->d_scan_tmp, s);
+    rc = pb_exclusive_scan_u32(p.item_off, p.item_off, slots, ctx->d_ctrl + 0, ctx->d_scan_tmp, s);
     if (rc != PB_OK) return rc;
     if (verified) break;
     PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
     PB_HIP(hipStreamSynchronize(s));
     const uint32_t need_items = ctx->h_ctrl[0], need_bins = ctx->h_ctrl[2];
     if (need_items <= (uint32_t)ctx->ws_item_cap && need_bins <= (uint32_t)ctx->ws_bin_cap) {
+      ctx->ws_items_needed = (int)need_items;
       std::memcpy(ctx->ws_key, key, sizeof(unsigned long long) * 6);
       verified = true;
       break;
@@ -178,6 +184,7 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
     if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
   }
   if (!verified) { pb_set_error("pb_render: bin workspace could not be sized"); return PB_ERR_CAPACITY; }
+  p.n_items_host = ctx->ws_items_needed;
   int rc = pb_launch_bin_fill_eval(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
   PB_HIP(hipEventRecord(ctx->ev[1], s));
@@ -217,6 +224,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
     p.lbvh_n = ctx->lb_n;
   }
   p.precise = ctx->precise ? 1 : 0;
+  p.slice = ctx->tune_slice; p.eval_waves = ctx->tune_waves; p.ablate = ctx->tune_ablate;
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
 
@@ -248,6 +256,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
     PB_HIP(hipStreamSynchronize(s));
     const uint32_t needed = ctx->h_ctrl[0];
     if (needed <= (uint32_t)ctx->ws_chunks) {
+      ctx->ws_items_needed = (int)needed;
       std::memcpy(ctx->ws_key, key, sizeof(key));
       verified = true;
       break;
@@ -256,6 +265,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
     if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
   }
   if (!verified) { pb_set_error("pb_render: candidate chunk pool could not be sized"); return PB_ERR_CAPACITY; }
+  p.n_items_host = ctx->ws_items_needed;
   int rc = pb_launch_eval_reduce(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
   PB_HIP(hipEventRecord(ctx->ev[1], s));
@@ -311,6 +321,9 @@ int pb_create(const pb_control* control, int device, pb_ctx** out) {
   PB_HIP(hipMalloc(&ctx->d_matrix, sizeof(float) * 16));
   PB_HIP(hipMalloc(&ctx->d_ctrl, sizeof(uint32_t) * 4));
   PB_HIP(hipHostMalloc(&ctx->h_ctrl, sizeof(uint32_t) * 4));
+  if (const char* e = std::getenv("PB_TUNE_SLICE")) { int v = std::atoi(e); if (v >= 32 && v <= PB_SLICE) ctx->tune_slice = v; }
+  if (const char* e = std::getenv("PB_TUNE_WAVES")) { int v = std::atoi(e); if (v == 0 || (v >= 64 && v <= (1 << 20))) ctx->tune_waves = v; }
+  if (const char* e = std::getenv("PB_TUNE_ABLATE")) ctx->tune_ablate = std::atoi(e);
   *out = ctx;
   return PB_OK;
 }
@@ -558,6 +571,11 @@ int pb_counters(pb_ctx* ctx, pb_stats* out) {
   ctx->stats.valid_hits = h[PB_CNT_VALID]; ctx->stats.nodes_visited = h[PB_CNT_NODES];
   ctx->stats.gate_passes = h[PB_CNT_GATED];
   ctx->stats.shortcut_wrong = h[PB_CNT_SHORTCUT_WRONG];
+  if (std::getenv("PB_DEBUG_TIMES") && h[PB_CNT_T_END]) {
+    const double t0 = (double)~h[PB_CNT_T_START_INV], td = (double)~h[PB_CNT_T_DRAIN_INV], te = (double)h[PB_CNT_T_END];
+    std::fprintf(stderr, "[pb] evaluation queue: %llu items, first wave leaves the empty queue at %.1f us, last wave ends at %.1f us\n",
+                 (unsigned long long)h[PB_CNT_ITEMS], (td - t0) * 0.01, (te - t0) * 0.01);
+  }
   *out = ctx->stats;
   return PB_OK;
 }

@@ -30,24 +30,26 @@ static_assert(sizeof(TriPrep) == 64, "TriPrep layout");
 // Everything HitCylinder (Intersections.h:313-346) derives from a segment alone,
 // computed once per segment with the reference's operation order, plus the
 // gate box and the radiance weight.  48 dwords = 192 B, 64-byte aligned so a
-// wave-uniform record is fetched with three s_load_dwordx16.
+// wave-uniform record is fetched with s_load_dwordx16.  The first 32 dwords are
+// all the default (fast) pair evaluation reads: two loads, one round trip.
 struct __attribute__((aligned(64))) SegFrame {
   float Rinv[9];   //  0.. 8  R_inv, m[col][row] at col*3+row
-  float Tinv[3];   //  9..11  T_inv == origin_prime for a camera ray from (0,0,0)
-  float c4;        // 12      4*c, c of Intersections.h:344-346
-  float Sinv;      // 13      1/|end-start|
+  float ox2, oz2;  //  9,10   2*T_inv.x, 2*T_inv.z
+  float c4;        // 11      4*c, c of Intersections.h:344-346
+  float oy;        // 12      T_inv.y (T_inv == origin_prime for a camera ray from (0,0,0))
+  float len;       // 13      |end-start|
   float tb0;       // 14      |start-orig_start|
-  float ox2, oz2;  // 15,16   2*Tinv.x, 2*Tinv.z
-  float R[9];      // 17..25  inverse(R_inv) (Intersections.h:443-444)
-  float bdir[3];   // 26..28  normalize(end-start)
-  float lo[3];     // 29..31  gate box, min_b of HitBoundingBox
-  float hi[3];     // 32..34  max_b
-  uint32_t qflags; // 35      bit i: origin inside slab i (MIDDLE); bit 3: origin inside the box;
+  uint32_t qflags; // 15      bit i: origin inside slab i (MIDDLE); bit 3: origin inside the box;
                    //         bit 4: the gate box contains the segment's cylinder
-  double W[3];     // 36..41  energy*(1/(4 PI))*(sigma_s/(PI r^2)) (721) or energy*(1/(4 PI)) (73het)
-  float cand[3];   // 42..44  candidate planes of HitBoundingBox for the origin (0,0,0)
-  float radius;    // 45
-  float len;       // 46      |end-start|
+  double W[3];     // 16..21  energy*(1/(4 PI))*(sigma_s/(PI r^2)) (721) or energy*(1/(4 PI)) (73het)
+  float lo[3];     // 22..24  gate box, min_b of HitBoundingBox
+  float hi[3];     // 25..27  max_b
+  float cand[3];   // 28..30  candidate planes of HitBoundingBox for the origin (0,0,0)
+  float Sinv;      // 31      1/|end-start|
+  float R[9];      // 32..40  inverse(R_inv) (Intersections.h:443-444)
+  float ox, oz;    // 41,42   T_inv.x, T_inv.z
+  float bdir[3];   // 43..45  normalize(end-start)
+  float radius;    // 46
   float pad;
 };
 static_assert(sizeof(SegFrame) == 192, "SegFrame layout");
@@ -113,9 +115,15 @@ struct RenderParams {
   uint32_t* sub_off;        // [macro tiles][PB_BIN_SUBS] start of each sub-list in bin_list (a macro tile's are adjacent)
   uint32_t* bin_list;       // [bin_capacity] segment indices, grouped by tile
   uint32_t* items;          // [items][4]: group, start, n, 0
-  uint32_t* item_off;       // [tiles] first item of the tile
+  uint32_t* item_off;       // [queue slots] first item of the tile in that slot (macro tiles in rank order)
+  uint32_t* macro_cnt;      // [macro tiles] list length
+  uint32_t* macro_rank;     // [macro tiles] position in the evaluation queue, longest list first
   unsigned long long* accum;// [out_h*out_w][3] fixed-point radiance sums
   int bin_capacity, item_capacity;
+  int n_items_host;         // number of items of this frame as measured when the workspace was sized
+  int slice;                // candidates of a macro list per evaluation item (<= PB_SLICE)
+  int eval_waves;           // size of the persistent evaluation grid
+  int ablate;               // tuning only (PB_TUNE_ABLATE): 1 skip the pixel atomics, 2 skip the pair loop, 4 skip refinement
   // LBVH (lbvh_n < 2: scan all segments)
   const LbvhNode* lbvh_nodes;
   const float4* lbvh_sA;    // capsules in Morton order
@@ -138,7 +146,10 @@ constexpr int PB_STACK_CAP = 2048;
 #define PB_FIX_SCALE 9.094947017729282e-13   /* 2^-40 */
 #define PB_FIX_LIMIT 2047.0                   /* larger contributions saturate here (display range is [0,1]) */
 
-enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_SHORTCUT_WRONG, PB_CNT_N };
+enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_SHORTCUT_WRONG,
+       // evaluation-queue timing of a counted frame, 100 MHz ticks: ~first wave start, ~first wave that found the
+       // queue empty (both stored as ~t so that atomicMax yields the minimum), last wave end; items processed
+       PB_CNT_T_START_INV, PB_CNT_T_DRAIN_INV, PB_CNT_T_END, PB_CNT_ITEMS, PB_CNT_N };
 
 void pb_set_error(const std::string& msg);
 
@@ -193,12 +204,12 @@ struct pb_ctx {
   uint32_t* d_ctrl = nullptr;
   uint32_t* h_ctrl = nullptr;          // pinned
   int ws_groups = 0, ws_chunks = 0;
-  uint32_t* d_tile_u32 = nullptr;      // tile_count | item_off (ws_tiles each) | sub_count | sub_fill | sub_off (macro)
+  uint32_t* d_tile_u32 = nullptr;      // tile_count | item_off | macro_cnt | macro_rank (ws_tiles each) | sub_count | sub_fill | sub_off
   uint32_t* d_bin_list = nullptr;
   uint32_t* d_items = nullptr;
   unsigned long long* d_accum = nullptr;
   uint32_t* d_scan_tmp = nullptr;
-  int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_scan_words = 0;
+  int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_scan_words = 0, ws_items_needed = 0;
   size_t ws_accum_px = 0;
   unsigned long long segs_version = 0; // bumped whenever the segment set or scene changes
   unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // frame geometry the chunk capacity was verified for
@@ -206,6 +217,8 @@ struct pb_ctx {
   unsigned long long* d_counters = nullptr;
   bool count_on = false;
   bool precise = false;
+  int tune_ablate = 0;
+  int tune_slice = 256, tune_waves = 0;   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
   pb_stats stats;
 };
 

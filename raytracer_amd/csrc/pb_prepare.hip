@@ -91,7 +91,7 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
   SegFrame f;
   for (int col = 0; col < 3; ++col)
     for (int row = 0; row < 3; ++row) { f.Rinv[col * 3 + row] = Rinv.m[col][row]; f.R[col * 3 + row] = R.m[col][row]; }
-  f.Tinv[0] = Tinv.x; f.Tinv[1] = Tinv.y; f.Tinv[2] = Tinv.z;
+  f.ox = Tinv.x; f.oy = Tinv.y; f.oz = Tinv.z;
   f.c4 = 4 * c;
   f.Sinv = Sinv;
   // |seg.start - seg.orig_start| as a vec4 length, w = 1 - 1 = 0  (Intersections.h:440)

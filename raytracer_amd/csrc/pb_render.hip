@@ -87,7 +87,7 @@ PB_DI int hit_cylinder_exact(const SegFrame& f, const Ray& r, CylHit& h) {
   float t1 = (-b - sq) / (2 * a);
   if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
   const float dpy = f.Rinv[1] * l.x + f.Rinv[4] * l.y + f.Rinv[7] * l.z;
-  const float ox = f.Tinv[0], oy = f.Tinv[1], oz = f.Tinv[2];
+  const float ox = f.ox, oy = f.oy, oz = f.oz;
   const float y0 = oy + t0 * dpy;
   const float y1 = oy + t1 * dpy;
   float thf = 0.0f, ths = 0.0f;
@@ -244,7 +244,7 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
   const float t0 = (-b - sq) * inv2a;     // a > 0: already ordered, t0 <= t1
   const float t1 = (-b + sq) * inv2a;
   const float dpy = __builtin_fmaf(f.Rinv[7], l.z, __builtin_fmaf(f.Rinv[4], l.y, f.Rinv[1] * l.x));
-  const float oy = f.Tinv[1];
+  const float oy = f.oy;
   const float y0 = __builtin_fmaf(t0, dpy, oy);
   const float y1 = __builtin_fmaf(t1, dpy, oy);
   float thf, ths = 0.0f;
@@ -487,6 +487,28 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   }
 }
 
+// Wave-uniform fetch of a segment's record through the scalar unit.  The loads are issued together and
+// waited for once: left to itself the compiler sinks every field's load into the branch that uses it,
+// which makes three dependent round trips to L2 per candidate.  WHOLE = false fetches the 32 dwords the
+// fast evaluation reads.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <bool WHOLE>
+PB_DI SegFrame fetch_frame(const SegFrame* frames, int sidx) {
+  const PB_CONST_AS u32x16* src = (const PB_CONST_AS u32x16*)pb_uniform(frames + sidx);
+  SegFrame f;
+  u32x16 q0 = src[0], q1 = src[1];
+  if (WHOLE) {
+    u32x16 q2 = src[2];
+    asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2));
+    __builtin_memcpy((char*)&f + 128, &q2, 64);
+  } else {
+    asm volatile("" : "+s"(q0), "+s"(q1));
+  }
+  __builtin_memcpy((char*)&f, &q0, 64);
+  __builtin_memcpy((char*)&f + 64, &q1, 64);
+  return f;
+}
+
 // Radiance weight times integral for one pair, by either estimator.
 template <bool COUNT, bool PRECISE, int MODE>
 PB_DI int eval_pair(const RenderParams& p, int sidx, const SegFrame& f, const Ray& r, double& integral,
@@ -510,11 +532,8 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
   unsigned long long c_cand = 0, c_cyl = 0, c_valid = 0, c_wrong = 0;
   const uint32_t produced = p.ctrl[0];
   const uint32_t n_chunks = produced < (uint32_t)p.chunk_capacity ? produced : (uint32_t)p.chunk_capacity;
-  while (true) {
-    uint32_t c = 0;
-    if (lane == 0) c = atomicAdd(&p.ctrl[1], 1u);
-    c = __builtin_amdgcn_readfirstlane(c);
-    if (c >= n_chunks) break;              // every wave reaches this: the counter only grows
+  // chunks are dealt round-robin over the grid (normally one wave per chunk): no shared work counter
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const PB_CONST_AS uint32_t* ch = pb_uniform(p.chunks + (size_t)c * PB_CHUNK_WORDS);
     const int group = (int)ch[0];
     const int n = (int)ch[1];
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
     double acc[3] = {0.0, 0.0, 0.0};
     for (int k = 0; k < n; ++k) {
       const int sidx = (int)ch[4 + k];
-      const SegFrame f = pb_uniform(p.frames)[sidx];
+      const SegFrame f = fetch_frame<PRECISE>(p.frames, sidx);
       double integral = 0.0;
       const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong);
       if (res == 2) {
@@ -736,45 +755,71 @@ __global__ __launch_bounds__(256) void bin_kernel(const RenderParams p) {
     }
 }
 
-// Items of a tile: the list of its macro tile cut into slices of PB_SLICE, for each sub-sample group.
-// A tile none of whose rays is active gets none.
-PB_DI uint32_t macro_count(const RenderParams& p, int m) {
+// Length of every macro tile's list (sum of its sub-counters).
+__global__ __launch_bounds__(256) void macro_count_kernel(const RenderParams p, int n_macro) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_macro) return;
   uint32_t cnt = 0;
   for (int k = 0; k < PB_BIN_SUBS; ++k) cnt += p.sub_count[(size_t)m * PB_BIN_SUBS + k];
-  return cnt;
+  p.macro_cnt[m] = cnt;
 }
 
+// Rank of every macro tile by list length, longest first (ties by index).  The evaluation queue is laid
+// out in this order: the items of the busiest tiles are started first and the short ones fill the gaps,
+// instead of a few long items being left running alone at the end of the kernel.
+__global__ __launch_bounds__(256) void macro_rank_kernel(const RenderParams p, int n_macro) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_macro) return;
+  const uint32_t mine = p.macro_cnt[m];
+  uint32_t rank = 0;
+  for (int j = 0; j < n_macro; ++j) {
+    const uint32_t c = p.macro_cnt[j];
+    rank += (c > mine || (c == mine && j < m)) ? 1u : 0u;
+  }
+  p.macro_rank[m] = rank;
+}
+
+// Queue slot of tile t: macro tiles in rank order, PB_MACRO^2 slots each.
+PB_DI int tile_slot(const RenderParams& p, int t, int& m) {
+  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
+  const int tx = t % p.tiles_x, tk = t / p.tiles_x;
+  m = (tk / PB_MACRO) * mtx + tx / PB_MACRO;
+  return (int)p.macro_rank[m] * (PB_MACRO * PB_MACRO) + (tk % PB_MACRO) * PB_MACRO + tx % PB_MACRO;
+}
+
+// Items of a tile: the list of its macro tile cut into slices of p.slice, for each sub-sample group.
+// A tile none of whose rays is active gets none.  item_off is indexed by queue slot.
 __global__ __launch_bounds__(256) void tile_items_kernel(const RenderParams p, int n_tiles) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tiles) return;
   const int nsub = p.ssaa * p.ssaa;
-  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
-  const int m = ((t / p.tiles_x) / PB_MACRO) * mtx + (t % p.tiles_x) / PB_MACRO;
-  const uint32_t cnt = macro_count(p, m);
+  int m;
+  const int slot = tile_slot(p, t, m);
+  const uint32_t cnt = p.macro_cnt[m];
   p.tile_count[t] = cnt;
   uint32_t n_items = 0;
   for (int q = 0; q < nsub; ++q)
-    if (p.group_last[t * nsub + q] >= 0) n_items += (cnt + PB_SLICE - 1) / PB_SLICE;
-  p.item_off[t] = n_items;
+    if (p.group_last[t * nsub + q] >= 0) n_items += (cnt + p.slice - 1) / p.slice;
+  p.item_off[slot] = n_items;
 }
 
 __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, int n_tiles) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tiles) return;
   const uint32_t cnt = p.tile_count[t];
-  const uint32_t slices = (cnt + PB_SLICE - 1) / PB_SLICE;
+  const uint32_t slices = (cnt + p.slice - 1) / p.slice;
   const int nsub = p.ssaa * p.ssaa;
-  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
-  const int m = ((t / p.tiles_x) / PB_MACRO) * mtx + (t % p.tiles_x) / PB_MACRO;
+  int m;
+  const int slot = tile_slot(p, t, m);
   const uint32_t list0 = p.sub_off[(size_t)m * PB_BIN_SUBS];
-  uint32_t it = p.item_off[t];
+  uint32_t it = p.item_off[slot];
   for (int q = 0; q < nsub; ++q) {
     if (p.group_last[t * nsub + q] < 0) continue;
     for (uint32_t c = 0; c < slices; ++c, ++it) {
       if (it >= (uint32_t)p.item_capacity) return;
       uint32_t* dst = p.items + (size_t)it * 4;
-      const uint32_t n = (cnt - c * PB_SLICE < (uint32_t)PB_SLICE) ? cnt - c * PB_SLICE : (uint32_t)PB_SLICE;
-      dst[0] = (uint32_t)(t * nsub + q); dst[1] = list0 + c * PB_SLICE; dst[2] = n; dst[3] = 0u;
+      const uint32_t n = (cnt - c * p.slice < (uint32_t)p.slice) ? cnt - c * p.slice : (uint32_t)p.slice;
+      dst[0] = (uint32_t)(t * nsub + q); dst[1] = list0 + c * p.slice; dst[2] = n; dst[3] = 0u;
     }
   }
 }
@@ -788,11 +833,12 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
   const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
   const int nsub = p.ssaa * p.ssaa;
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
-  while (true) {
-    uint32_t c = 0;
-    if (lane == 0) c = atomicAdd(&p.ctrl[1], 1u);
-    c = __builtin_amdgcn_readfirstlane(c);
-    if (c >= n_items) break;              // every wave reaches this: the counter only grows
+  if (COUNT && lane == 0) atomicMax(&p.counters[PB_CNT_T_START_INV], ~(unsigned long long)wall_clock64());
+  // Items are dealt round-robin: wave w takes items w, w + grid, w + 2 grid, ...  The queue is sorted by
+  // weight (longest lists first), so every wave gets a similar mix; a shared work counter costs about 12 ns
+  // per item on this chip (all waves hit one address) and was most of the kernel time.
+  for (uint32_t c = blockIdx.x; c < n_items; c += gridDim.x) {
+    if (COUNT && lane == 0) atomicAdd(&p.counters[PB_CNT_ITEMS], 1ull);
     const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
     const int group = (int)it[0];
     const uint32_t start = it[1];
@@ -803,7 +849,7 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
     V3 pl[4];
     tile_planes(p, tx, tk, pl);
     int ns = 0;
-    for (int base = 0; base < n; base += 64) {
+    for (int base = 0; base < ((p.ablate & 4) ? 0 : n); base += 64) {
       const int k = base + lane;
       bool touch = false;
       uint32_t sidx = 0;
@@ -825,9 +871,11 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
     r.active = r.maxd >= 0.0f;
     unsigned long long ai[3] = {0ull, 0ull, 0ull};
     uint32_t nc = 0;
+    int sidx = ns > 0 ? __builtin_amdgcn_readfirstlane((int)surv[0]) : 0;
+    if (p.ablate & 2) ns = 0;
     for (int k = 0; k < ns; ++k) {
-      const int sidx = __builtin_amdgcn_readfirstlane((int)surv[k]);
-      const SegFrame f = pb_uniform(p.frames)[sidx];
+      const uint32_t next_idx = surv[(k + 1 < ns) ? k + 1 : k];   // read now, needed at the end of the iteration
+      const SegFrame f = fetch_frame<PRECISE>(p.frames, sidx);
       double integral = 0.0;
       const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong);
       if (res == 2) {
@@ -841,9 +889,10 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
         nc++;
       }
       if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
+      sidx = __builtin_amdgcn_readfirstlane((int)next_idx);
     }
     __syncthreads();   // surv is rewritten by the next item
-    if (nc) {
+    if (nc && !(p.ablate & 1)) {
       const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
       unsigned long long* dst = p.accum + ((size_t)oy * p.out_w + ox) * 3;   // active lanes are inside the image
       const unsigned long long bias = (unsigned long long)nc * magic_bits;
@@ -853,6 +902,7 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
     }
   }
   if (COUNT) {
+    if (lane == 0) atomicMax(&p.counters[PB_CNT_T_DRAIN_INV], ~(unsigned long long)wall_clock64());
     unsigned long long v[4] = {c_cand, c_cyl, c_valid, c_wrong};
     const int slot[4] = {PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_SHORTCUT_WRONG};
     for (int k = 0; k < 4; ++k) {
@@ -860,6 +910,7 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
       if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
     }
+    if (lane == 0) atomicMax(&p.counters[PB_CNT_T_END], (unsigned long long)wall_clock64());
   }
 }
 
@@ -892,7 +943,8 @@ int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
-  int waves = p.chunk_capacity < PB_EVAL_WAVES ? p.chunk_capacity : PB_EVAL_WAVES;
+  int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;   // one wave per chunk
+  if (waves > p.chunk_capacity) waves = p.chunk_capacity;
   if (waves < 1) waves = 1;
   if (mode == PB_MODE_73HET) {
     if (count) hipLaunchKernelGGL((eval_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
@@ -921,7 +973,10 @@ int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
 int pb_launch_bin_count(const RenderParams& p, hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
+  const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
   if (p.n_seg > 0) hipLaunchKernelGGL(bin_kernel<false>, dim3((p.n_seg + 255) / 256), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(macro_count_kernel, dim3((n_macro + 255) / 256), dim3(256), 0, s, p, n_macro);
+  hipLaunchKernelGGL(macro_rank_kernel, dim3((n_macro + 255) / 256), dim3(256), 0, s, p, n_macro);
   hipLaunchKernelGGL(tile_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
   PB_HIP(hipGetLastError());
   return PB_OK;
@@ -932,7 +987,9 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   if (tiles <= 0) return PB_OK;
   if (p.n_seg > 0) hipLaunchKernelGGL(bin_kernel<true>, dim3((p.n_seg + 255) / 256), dim3(256), 0, s, p);
   hipLaunchKernelGGL(make_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
-  int waves = p.item_capacity < PB_EVAL_WAVES ? p.item_capacity : PB_EVAL_WAVES;
+  // one wave per item when PB_TUNE_WAVES=0: the hardware dispatcher then hands out the queue in order
+  int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;
+  if (waves > p.item_capacity) waves = p.item_capacity;
   if (waves < 1) waves = 1;
   if (mode == PB_MODE_73HET) {
     if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
