@@ -154,21 +154,26 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
       p.macro_cnt = ctx->d_tile_u32 + 2 * T; p.macro_rank = ctx->d_tile_u32 + 3 * T;
       p.sub_count = ctx->d_tile_u32 + 4 * T; p.sub_fill = p.sub_count + T * PB_BIN_SUBS; p.sub_off = p.sub_fill + T * PB_BIN_SUBS;
     }
-    PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
     p.bin_list = ctx->d_bin_list; p.items = ctx->d_items; p.accum = ctx->d_accum;
     p.bin_capacity = ctx->ws_bin_cap; p.item_capacity = ctx->ws_item_cap;
-    PB_HIP(hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * 4, s));
-    PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ctx->ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
-    PB_HIP(hipMemsetAsync(ctx->d_accum, 0, sizeof(unsigned long long) * 3 * px, s));
+    p.fused_queue = (tiles <= pb_fused_queue_tiles()) ? 1 : 0;
     PB_HIP(hipEventRecord(ctx->ev[0], s));
+    if (!p.fused_queue) {
+      PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
+      PB_HIP(hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * 4, s));
+      PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ctx->ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
+      PB_HIP(hipMemsetAsync(ctx->d_accum, 0, sizeof(unsigned long long) * 3 * px, s));
+    }
     rc = pb_launch_ray_setup(p, ctx->count_on, s);
     if (rc != PB_OK) return rc;
-    rc = pb_launch_bin_count(p, s);
+    rc = pb_launch_bin_count(p, s);     // count pass, then (small frames) the whole queue in one block
     if (rc != PB_OK) return rc;
-    rc = pb_exclusive_scan_u32(p.sub_count, p.sub_off, mtiles * PB_BIN_SUBS, ctx->d_ctrl + 2, ctx->d_scan_tmp, s);
-    if (rc != PB_OK) return rc;
-    rc = pb_exclusive_scan_u32(p.item_off, p.item_off, slots, ctx->d_ctrl + 0, ctx->d_scan_tmp, s);
-    if (rc != PB_OK) return rc;
+    if (!p.fused_queue) {
+      rc = pb_exclusive_scan_u32(p.sub_count, p.sub_off, mtiles * PB_BIN_SUBS, ctx->d_ctrl + 2, ctx->d_scan_tmp, s);
+      if (rc != PB_OK) return rc;
+      rc = pb_exclusive_scan_u32(p.item_off, p.item_off, slots, ctx->d_ctrl + 0, ctx->d_scan_tmp, s);
+      if (rc != PB_OK) return rc;
+    }
     if (verified) break;
     PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
     PB_HIP(hipStreamSynchronize(s));

@@ -120,6 +120,7 @@ struct RenderParams {
   uint32_t* macro_rank;     // [macro tiles] position in the evaluation queue, longest list first
   unsigned long long* accum;// [out_h*out_w][3] fixed-point radiance sums
   int bin_capacity, item_capacity;
+  int fused_queue;          // 1: ray set-up clears the accumulators and one block builds the queue (small frames)
   int n_items_host;         // number of items of this frame as measured when the workspace was sized
   int slice;                // candidates of a macro list per evaluation item (<= PB_SLICE)
   int eval_waves;           // size of the persistent evaluation grid
@@ -137,7 +138,8 @@ constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 51
 constexpr int PB_EVAL_WAVES = 256 * 32;
 constexpr int PB_MACRO = 8;             // a macro tile is PB_MACRO x PB_MACRO tiles (64 x 64 pixels)
 constexpr int PB_SLICE = 512;           // candidates of a macro list handed to one evaluation item
-constexpr int PB_BIN_SUBS = 32;         // sub-counters per tile in the binning passes (power of two)
+constexpr int PB_BIN_FAN = 8;            // lanes that share the macro rows of one segment in the binning passes
+constexpr int PB_BIN_SUBS = 1;          // sub-counters per tile in the binning passes (power of two)
 constexpr int PB_STACK_CAP = 2048;
 // Fixed-point radiance accumulation of the binned path: contributions are rounded to multiples of 2^-40
 // (9e-13) by adding PB_FIX_MAGIC = 1.5 * 2^12 in double, and summed as 64-bit integers, so the sum does
@@ -218,7 +220,7 @@ struct pb_ctx {
   bool count_on = false;
   bool precise = false;
   int tune_ablate = 0;
-  int tune_slice = 256, tune_waves = 0;   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
+  int tune_slice = 192, tune_waves = 0;   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
   pb_stats stats;
 };
 
@@ -246,6 +248,7 @@ int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);
 int pb_launch_bin_count(const RenderParams& p, hipStream_t s);
+int pb_fused_queue_tiles(void);
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s);
 
 #endif

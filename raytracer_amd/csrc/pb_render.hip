@@ -407,6 +407,17 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + ly;
   const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
 
+  if (p.fused_queue) {
+    // this launch also clears what the frame accumulates into: the pixel sums and the bin counters
+    if (sub == 0 && ox < p.out_w && oy < p.out_h) {
+      unsigned long long* a = p.accum + ((size_t)oy * p.out_w + ox) * 3;
+      a[0] = 0ull; a[1] = 0ull; a[2] = 0ull;
+    }
+    if (group == 0) {
+      const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
+      for (int i = lane; i < n_macro; i += 64) { p.sub_count[i] = 0u; p.sub_fill[i] = 0u; }
+    }
+  }
   Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
   r.active = r.active && in_image;
   // the root gate is a property of the ray alone (BeamRadiance.h:426-430 at the tree root)
@@ -624,6 +635,17 @@ __global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
   const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
   const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + (lane >> 3);
   const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
+  if (p.fused_queue) {
+    // this launch also clears what the frame accumulates into: the pixel sums and the bin counters
+    if (sub == 0 && ox < p.out_w && oy < p.out_h) {
+      unsigned long long* a = p.accum + ((size_t)oy * p.out_w + ox) * 3;
+      a[0] = 0ull; a[1] = 0ull; a[2] = 0ull;
+    }
+    if (group == 0) {
+      const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
+      for (int i = lane; i < n_macro; i += 64) { p.sub_count[i] = 0u; p.sub_fill[i] = 0u; }
+    }
+  }
   Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
   r.active = r.active && in_image;
   const bool hit_scene = r.active;
@@ -664,17 +686,6 @@ PB_DI void pixel_rect_planes(const RenderParams& p, int px0, int px1, int py0, i
   pl[1] = normalize3(v3(-p.focal, 0.0f, xr));
   pl[2] = normalize3(v3(0.0f, p.focal, -yt));
   pl[3] = normalize3(v3(0.0f, -p.focal, yb));
-}
-
-// Macro tile (mx, my): PB_MACRO x PB_MACRO tiles.  With interleaved strips its tile rows are
-// strip_stride apart; the pyramid then also spans the rows in between (conservative).
-PB_DI void macro_planes(const RenderParams& p, int mx, int my, V3 pl[4]) {
-  const int tx0 = mx * PB_MACRO, tk0 = my * PB_MACRO;
-  int tx1 = tx0 + PB_MACRO - 1, tk1 = tk0 + PB_MACRO - 1;
-  if (tx1 > p.tiles_x - 1) tx1 = p.tiles_x - 1;
-  if (tk1 > p.tiles_y - 1) tk1 = p.tiles_y - 1;
-  pixel_rect_planes(p, p.x0 + 8 * tx0, p.x0 + 8 * tx1 + 7, p.y0 + 8 * tk0 * p.strip_stride,
-                    p.y0 + 8 * tk1 * p.strip_stride + 7, pl);
 }
 
 // Is some point of the axis a-b within `slack` of all four half-spaces at once?  Clips the parameter
@@ -730,29 +741,99 @@ PB_DI TileRect macro_rect(const RenderParams& p, V3 a, V3 b, float pad, int mtx,
   return r;
 }
 
-// One lane per segment: append the segment to every macro tile its axis can touch.
-template <bool FILL>
-__global__ __launch_bounds__(256) void bin_kernel(const RenderParams p) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= p.n_seg) return;
-  const float4 A4 = p.capA[s], B4 = p.capB[s];
+// Clip the parameter interval [t0, t1] of the axis a-b (widened by `slack`) with the half-space n.x >= 0.
+PB_DI bool clip_axis(const V3 n, const float4 A, const float4 B, float slack, float& t0, float& t1) {
+  const float fa = n.x * A.x + n.y * A.y + n.z * A.z + slack;
+  const float fb = n.x * B.x + n.y * B.y + n.z * B.z + slack;
+  if (fa < 0.0f && fb < 0.0f) return false;
+  const float t = fa * fast_rcp(fa - fb);          // only used when fa and fb differ in sign
+  if (fa < 0.0f && fb >= 0.0f) t0 = fmaxf(t0, t - 1e-5f);
+  if (fb < 0.0f && fa >= 0.0f) t1 = fminf(t1, t + 1e-5f);
+  return t0 <= t1;
+}
+
+// Visits every macro tile the axis of segment s can touch, for the rows my0 + k, my0 + k + PB_BIN_FAN, ...
+// of its rectangle: clips the axis with the row's two planes, then with each column's.
+template <class F>
+PB_DI void for_each_macro_tile(const RenderParams& p, const float4 A4, const float4 B4, int k, int mtx, int mty, F&& hit) {
   const float pad = A4.w * 1.001f + 1e-5f;
-  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO, mty = (p.tiles_y + PB_MACRO - 1) / PB_MACRO;
   const TileRect rc = macro_rect(p, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), pad, mtx, mty);
-  for (int my = rc.y0; my <= rc.y1; ++my)
+  const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
+  for (int my = rc.y0 + k; my <= rc.y1; my += PB_BIN_FAN) {
+    // rows of the macro tile (with interleaved strips its tile rows are strip_stride apart; the pyramid
+    // then also spans the rows in between: conservative)
+    const int tk0 = my * PB_MACRO;
+    int tk1 = tk0 + PB_MACRO - 1;
+    if (tk1 > p.tiles_y - 1) tk1 = p.tiles_y - 1;
+    const int py0 = p.y0 + 8 * tk0 * p.strip_stride, py1 = p.y0 + 8 * tk1 * p.strip_stride + 7;
+    const float yt = (float)(py0 * p.ssaa) - half_h - 0.5f;
+    const float yb = (float)(py1 * p.ssaa + p.ssaa - 1) - half_h + 0.5f;
+    float r0 = -1e-5f, r1 = 1.0f + 1e-5f;
+    if (!clip_axis(normalize3(v3(0.0f, p.focal, -yt)), A4, B4, pad, r0, r1)) continue;
+    if (!clip_axis(normalize3(v3(0.0f, -p.focal, yb)), A4, B4, pad, r0, r1)) continue;
     for (int mx = rc.x0; mx <= rc.x1; ++mx) {
-      V3 pl[4];
-      macro_planes(p, mx, my, pl);
-      if (!axis_touches_pyramid(A4, B4, pl)) continue;
-      // PB_BIN_SUBS counters per macro tile, picked by the segment index: a tile over the light source
-      // receives every beam, and that many atomics on one address would serialise
-      const size_t slot = (size_t)(my * mtx + mx) * PB_BIN_SUBS + ((uint32_t)s & (PB_BIN_SUBS - 1));
-      if (FILL) {
-        const uint32_t pos = atomicAdd(&p.sub_fill[slot], 1u);
-        const uint32_t at = p.sub_off[slot] + pos;
-        if (at < (uint32_t)p.bin_capacity) p.bin_list[at] = (uint32_t)s;
-      } else atomicAdd(&p.sub_count[slot], 1u);
+      const int tx0 = mx * PB_MACRO;
+      int tx1 = tx0 + PB_MACRO - 1;
+      if (tx1 > p.tiles_x - 1) tx1 = p.tiles_x - 1;
+      const int px0 = p.x0 + 8 * tx0, px1 = p.x0 + 8 * tx1 + 7;
+      const float xl = (float)(px0 * p.ssaa) - half_w - 0.5f;
+      const float xr = (float)(px1 * p.ssaa + p.ssaa - 1) - half_w + 0.5f;
+      float t0 = r0, t1 = r1;
+      if (!clip_axis(normalize3(v3(p.focal, 0.0f, -xl)), A4, B4, pad, t0, t1)) continue;
+      if (!clip_axis(normalize3(v3(-p.focal, 0.0f, xr)), A4, B4, pad, t0, t1)) continue;
+      hit(my * mtx + mx);
     }
+  }
+}
+
+// Binning passes.  A block takes 128 segments, PB_BIN_FAN lanes each (a long beam crosses the whole
+// image; one lane per segment walked up to 64 macro tiles one after the other).  Hits are first counted
+// per macro tile in LDS, so that a block issues one global atomic per macro tile it touches instead of
+// one per hit: every beam passes the tile over the light source, and device-wide atomics on few
+// addresses run at about one per 12 ns.  The filling pass reserves a range per (block, macro tile) the
+// same way and then walks the tiles a second time to place its segments inside the range.
+// LDS = false (more macro tiles than fit in LDS): plain global atomics.
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_LDS_MACROS = 4096;      // 2 x 4096 x 4 B = 32 KB of LDS
+template <bool FILL, bool LDS>
+__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const RenderParams p, int n_macro) {
+  extern __shared__ uint32_t bin_lds[];      // [n_macro] counts, [n_macro] bases
+  uint32_t* lcount = bin_lds;
+  uint32_t* lbase = bin_lds + n_macro;
+  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO, mty = (p.tiles_y + PB_MACRO - 1) / PB_MACRO;
+  const long long g = (long long)blockIdx.x * BIN_THREADS + threadIdx.x;
+  const int s = (int)(g / PB_BIN_FAN), k = (int)(g % PB_BIN_FAN);
+  const bool live = s < p.n_seg;
+  float4 A4 = make_float4(0, 0, 1, 0), B4 = A4;
+  if (live) { A4 = p.capA[s]; B4 = p.capB[s]; }
+  if (!LDS) {
+    if (!live) return;
+    for_each_macro_tile(p, A4, B4, k, mtx, mty, [&](int m) {
+      if (FILL) {
+        const uint32_t at = p.sub_off[m] + atomicAdd(&p.sub_fill[m], 1u);
+        if (at < (uint32_t)p.bin_capacity) p.bin_list[at] = (uint32_t)s;
+      } else atomicAdd(&p.sub_count[m], 1u);
+    });
+    return;
+  }
+  for (int m = threadIdx.x; m < n_macro; m += BIN_THREADS) lcount[m] = 0u;
+  __syncthreads();
+  if (live) for_each_macro_tile(p, A4, B4, k, mtx, mty, [&](int m) { atomicAdd(&lcount[m], 1u); });
+  __syncthreads();
+  for (int m = threadIdx.x; m < n_macro; m += BIN_THREADS) {
+    const uint32_t c = lcount[m];
+    if (c) {
+      if (FILL) lbase[m] = p.sub_off[m] + atomicAdd(&p.sub_fill[m], c);
+      else atomicAdd(&p.sub_count[m], c);
+    }
+    lcount[m] = 0u;
+  }
+  if (!FILL) return;
+  __syncthreads();
+  if (live) for_each_macro_tile(p, A4, B4, k, mtx, mty, [&](int m) {
+    const uint32_t at = lbase[m] + atomicAdd(&lcount[m], 1u);
+    if (at < (uint32_t)p.bin_capacity) p.bin_list[at] = (uint32_t)s;
+  });
 }
 
 // Length of every macro tile's list (sum of its sub-counters).
@@ -824,9 +905,84 @@ __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, i
   }
 }
 
+// The steps between the two binning passes in one block (frames of up to QUEUE_FUSED_TILES tiles):
+// list offsets of the macro tiles, their rank by list length, items per queue slot and their prefix sum.  Small frames spend more time between launches than in these steps.
+constexpr int QUEUE_FUSED_TILES = 16384;           // 256 macro tiles, 16384 queue slots
+constexpr int QUEUE_THREADS = 1024;
+__global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const RenderParams p, int n_macro) {
+  __shared__ uint32_t s_cnt[256], s_inv[256], s_part[QUEUE_THREADS / 64];
+  const int t = threadIdx.x;
+  const int nsub = p.ssaa * p.ssaa;
+  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
+  if (t < n_macro) s_cnt[t] = p.sub_count[t];
+  __syncthreads();
+  if (t < n_macro) {
+    const uint32_t mine = s_cnt[t];
+    uint32_t off = 0, rank = 0;
+    for (int j = 0; j < n_macro; ++j) {
+      const uint32_t c = s_cnt[j];
+      off += (j < t) ? c : 0u;
+      rank += (c > mine || (c == mine && j < t)) ? 1u : 0u;
+    }
+    s_inv[rank] = (uint32_t)t;
+    p.sub_off[t] = off; p.macro_cnt[t] = mine; p.macro_rank[t] = rank;
+    if (t == n_macro - 1) p.ctrl[2] = off + mine;
+  }
+  __syncthreads();
+  const int slots = n_macro * PB_MACRO * PB_MACRO;
+  const int per = (slots + QUEUE_THREADS - 1) / QUEUE_THREADS;
+  const int slot0 = t * per;
+  // tile, list length and number of active groups of a slot; tile < 0: no tile there
+  auto slot_info = [&](int slot, uint32_t& cnt, uint32_t& m) -> int {
+    m = s_inv[slot / (PB_MACRO * PB_MACRO)];
+    const int local = slot % (PB_MACRO * PB_MACRO);
+    const int tx = (int)(m % mtx) * PB_MACRO + local % PB_MACRO, tk = (int)(m / mtx) * PB_MACRO + local / PB_MACRO;
+    cnt = s_cnt[m];
+    return (tx < p.tiles_x && tk < p.tiles_y) ? tk * p.tiles_x + tx : -1;
+  };
+  uint32_t mine_items = 0;
+  for (int slot = slot0; slot < slot0 + per && slot < slots; ++slot) {
+    uint32_t cnt, m;
+    const int tile = slot_info(slot, cnt, m);
+    if (tile < 0) continue;
+    const uint32_t slices = (cnt + p.slice - 1) / p.slice;
+    for (int q = 0; q < nsub; ++q)
+      if (p.group_last[tile * nsub + q] >= 0) mine_items += slices;
+  }
+  // block-wide exclusive scan of mine_items: in-wave shuffles, then the 16 wave totals
+  uint32_t incl = mine_items;
+  const int lane = t & 63, wave = t >> 6;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < QUEUE_THREADS / 64; ++w) { const uint32_t v = s_part[w]; s_part[w] = run; run += v; }
+    p.ctrl[0] = run;
+  }
+  __syncthreads();
+  uint32_t it = s_part[wave] + incl - mine_items;
+  // first item of every slot; make_items_kernel writes the items
+  for (int slot = slot0; slot < slot0 + per && slot < slots; ++slot) {
+    uint32_t cnt, m;
+    const int tile = slot_info(slot, cnt, m);
+    p.item_off[slot] = it;
+    if (tile < 0) continue;
+    p.tile_count[tile] = cnt;
+    const uint32_t slices = (cnt + p.slice - 1) / p.slice;
+    for (int q = 0; q < nsub; ++q)
+      if (p.group_last[tile * nsub + q] >= 0) it += slices;
+  }
+}
+
+#ifndef REFINE_UNROLL
+#define REFINE_UNROLL 1
+#endif
 template <bool COUNT, bool PRECISE, int MODE>
-__global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
-  __shared__ uint32_t surv[PB_SLICE];
+PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
   const int lane = threadIdx.x;
   unsigned long long c_cand = 0, c_cyl = 0, c_valid = 0, c_wrong = 0;
   const uint32_t produced = p.ctrl[0];
@@ -845,24 +1001,8 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
     const int n = (int)it[2];
     const int tile = group / nsub;
     const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
-    // 1. lanes test 64 candidates of the macro list at a time against this tile's pyramid
     V3 pl[4];
     tile_planes(p, tx, tk, pl);
-    int ns = 0;
-    for (int base = 0; base < ((p.ablate & 4) ? 0 : n); base += 64) {
-      const int k = base + lane;
-      bool touch = false;
-      uint32_t sidx = 0;
-      if (k < n) {
-        sidx = p.bin_list[start + k];
-        touch = axis_touches_pyramid(p.capA[sidx], p.capB[sidx], pl);
-      }
-      const unsigned long long mask = __ballot(touch);
-      if (touch) surv[ns + (int)lanes_below(mask)] = sidx;
-      ns += __builtin_popcountll(mask);
-    }
-    __syncthreads();
-    // 2. every lane evaluates its own ray against each survivor (wave-uniform record, scalar loads)
     const float* rr = p.rays + (size_t)group * 8 * 64;
     Ray r;
     r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
@@ -871,27 +1011,54 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
     r.active = r.maxd >= 0.0f;
     unsigned long long ai[3] = {0ull, 0ull, 0ull};
     uint32_t nc = 0;
-    int sidx = ns > 0 ? __builtin_amdgcn_readfirstlane((int)surv[0]) : 0;
-    if (p.ablate & 2) ns = 0;
-    for (int k = 0; k < ns; ++k) {
-      const uint32_t next_idx = surv[(k + 1 < ns) ? k + 1 : k];   // read now, needed at the end of the iteration
-      const SegFrame f = fetch_frame<PRECISE>(p.frames, sidx);
-      double integral = 0.0;
-      const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong);
-      if (res == 2) {
-        if (MODE == PB_MODE_73HET) {
-          // 1/sin(theta) is unbounded for a beam seen end-on: saturate far above the display range
-          integral = fmin(integral, PB_FIX_LIMIT / fmax(f.W[0], fmax(f.W[1], f.W[2])));
+    {
+      const int cbase = 0, cn = n;             // n <= PB_SLICE, the capacity of surv
+      // 1. lanes test the candidates against this tile's pyramid, REFINE_UNROLL x 64 at a time;
+      //    survivors are compacted into LDS
+      int ns = 0;
+      for (int base = 0; base < ((p.ablate & 4) ? 0 : cn); base += 64 * REFINE_UNROLL) {
+        uint32_t cand[REFINE_UNROLL];
+        float4 ca[REFINE_UNROLL], cb[REFINE_UNROLL];
+#pragma unroll
+        for (int j = 0; j < REFINE_UNROLL; ++j) {
+          const int k = base + j * 64 + lane;
+          cand[j] = (k < cn) ? p.bin_list[start + cbase + k] : 0xffffffffu;
         }
-        ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
-        ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[1], integral, PB_FIX_MAGIC));
-        ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[2], integral, PB_FIX_MAGIC));
-        nc++;
+#pragma unroll
+        for (int j = 0; j < REFINE_UNROLL; ++j)
+          if (cand[j] != 0xffffffffu) { ca[j] = p.capA[cand[j]]; cb[j] = p.capB[cand[j]]; }
+#pragma unroll
+        for (int j = 0; j < REFINE_UNROLL; ++j) {
+          const bool touch = (cand[j] != 0xffffffffu) && axis_touches_pyramid(ca[j], cb[j], pl);
+          const unsigned long long mask = __ballot(touch);
+          if (touch) surv[ns + (int)lanes_below(mask)] = cand[j];
+          ns += __builtin_popcountll(mask);
+        }
       }
-      if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
-      sidx = __builtin_amdgcn_readfirstlane((int)next_idx);
+      __syncthreads();
+      // 2. every lane evaluates its own ray against each survivor (wave-uniform record, scalar loads)
+      int sidx = ns > 0 ? __builtin_amdgcn_readfirstlane((int)surv[0]) : 0;
+      if (p.ablate & 2) ns = 0;
+      for (int k = 0; k < ns; ++k) {
+        const uint32_t next_idx = surv[(k + 1 < ns) ? k + 1 : k];   // read now, needed at the end of the iteration
+        const SegFrame f = fetch_frame<PRECISE>(p.frames, sidx);
+        double integral = 0.0;
+        const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong);
+        if (res == 2) {
+          if (MODE == PB_MODE_73HET) {
+            // 1/sin(theta) is unbounded for a beam seen end-on: saturate far above the display range
+            integral = fmin(integral, PB_FIX_LIMIT / fmax(f.W[0], fmax(f.W[1], f.W[2])));
+          }
+          ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
+          ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[1], integral, PB_FIX_MAGIC));
+          ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[2], integral, PB_FIX_MAGIC));
+          nc++;
+        }
+        if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
+        sidx = __builtin_amdgcn_readfirstlane((int)next_idx);
+      }
+      __syncthreads();   // surv is rewritten by the next item
     }
-    __syncthreads();   // surv is rewritten by the next item
     if (nc && !(p.ablate & 1)) {
       const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
       unsigned long long* dst = p.accum + ((size_t)oy * p.out_w + ox) * 3;   // active lanes are inside the image
@@ -914,6 +1081,19 @@ __global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
   }
 }
 
+template <bool COUNT, bool PRECISE, int MODE>
+__global__ __launch_bounds__(64) void eval_bins_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  eval_bins_body<COUNT, PRECISE, MODE>(p, surv);
+}
+
+// The default estimator at eight waves per SIMD (64 VGPRs, two of them spilled): the pair loop waits on
+// the scalar loads of the next record, and resident waves are what hides that.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_bins_fast_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  eval_bins_body<false, false, PB_MODE_721>(p, surv);
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)p.out_w * p.out_h;
@@ -926,6 +1106,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
 }
 
 }  // namespace
+
+int pb_fused_queue_tiles(void) { return QUEUE_FUSED_TILES; }
 
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
   (void)mode;
@@ -974,10 +1156,19 @@ int pb_launch_bin_count(const RenderParams& p, hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
   const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
-  if (p.n_seg > 0) hipLaunchKernelGGL(bin_kernel<false>, dim3((p.n_seg + 255) / 256), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(macro_count_kernel, dim3((n_macro + 255) / 256), dim3(256), 0, s, p, n_macro);
-  hipLaunchKernelGGL(macro_rank_kernel, dim3((n_macro + 255) / 256), dim3(256), 0, s, p, n_macro);
-  hipLaunchKernelGGL(tile_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
+  if (p.n_seg > 0) {
+    const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
+    if (n_macro <= BIN_LDS_MACROS)
+      hipLaunchKernelGGL((bin_kernel<false, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);
+    else hipLaunchKernelGGL((bin_kernel<false, false>), dim3(blocks), dim3(BIN_THREADS), 0, s, p, n_macro);
+  }
+  if (p.fused_queue) {
+    hipLaunchKernelGGL(queue_build_kernel, dim3(1), dim3(QUEUE_THREADS), 0, s, p, n_macro);
+  } else {
+    hipLaunchKernelGGL(macro_count_kernel, dim3((n_macro + 255) / 256), dim3(256), 0, s, p, n_macro);
+    hipLaunchKernelGGL(macro_rank_kernel, dim3((n_macro + 255) / 256), dim3(256), 0, s, p, n_macro);
+    hipLaunchKernelGGL(tile_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
+  }
   PB_HIP(hipGetLastError());
   return PB_OK;
 }
@@ -985,7 +1176,13 @@ int pb_launch_bin_count(const RenderParams& p, hipStream_t s) {
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
-  if (p.n_seg > 0) hipLaunchKernelGGL(bin_kernel<true>, dim3((p.n_seg + 255) / 256), dim3(256), 0, s, p);
+  if (p.n_seg > 0) {
+    const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
+    const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
+    if (n_macro <= BIN_LDS_MACROS)
+      hipLaunchKernelGGL((bin_kernel<true, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);
+    else hipLaunchKernelGGL((bin_kernel<true, false>), dim3(blocks), dim3(BIN_THREADS), 0, s, p, n_macro);
+  }
   hipLaunchKernelGGL(make_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
   // one wave per item when PB_TUNE_WAVES=0: the hardware dispatcher then hands out the queue in order
   int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;
@@ -998,7 +1195,7 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   else if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (p.precise) hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL((eval_bins_kernel<false, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(eval_bins_fast_kernel, dim3(waves), dim3(64), 0, s, p);
   const size_t px = (size_t)p.out_w * p.out_h;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, p);
   PB_HIP(hipGetLastError());
