@@ -148,3 +148,30 @@ def test_empty_segment_set_and_errors(pb):
         assert img.shape == (64, 64, 3) and not img.any()
         with pytest.raises(pb.PhotonBeamsError):
             ctx.draw(0, 0, 65, 1)                    # rectangle exceeds the screen
+
+
+def test_large_frame_takes_the_multi_kernel_queue_path(pb):
+    """Frames above 16384 tiles build the evaluation queue with the multi-kernel path (device-wide
+    scans) instead of the single-block one: 1160 x 1096 pixels = 145 x 137 tiles.  All three candidate
+    searches must agree, and a sparse lattice of pixels must match the oracle."""
+    kw = dict(photon_number=300, bounces=1, screen_width=1160, screen_height=1096)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        ctx.build_tree()
+        scan = ctx.draw(cull="scan").astype(np.float64)
+        lbvh = ctx.draw(cull="lbvh").astype(np.float64)
+        bins = ctx.draw(cull="bins").astype(np.float64)
+        bins2 = ctx.draw(cull="bins")
+    np.testing.assert_allclose(lbvh, scan, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(bins, scan, rtol=1e-5, atol=1e-7)
+    assert np.array_equal(bins.astype(np.float32), bins2)
+    tri, _ = orc.load_test_model()
+    ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
+                                   segs, lo, hi, 3, 5, 72, 68, step_x=16, step_y=16)
+    got = bins[5::16, 3::16][:68, :72]
+    err = np.abs(got - ref)
+    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), err.max()
+    assert np.sqrt((err ** 2).mean()) <= 1e-4 and ref.max() > 0.1
