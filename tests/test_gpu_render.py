@@ -175,3 +175,27 @@ def test_large_frame_takes_the_multi_kernel_queue_path(pb):
     err = np.abs(got - ref)
     assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), err.max()
     assert np.sqrt((err ** 2).mean()) <= 1e-4 and ref.max() > 0.1
+
+
+@pytest.mark.parametrize("ssaa", [2, 3])
+def test_supersampling_matches_oracle(pb, ssaa):
+    """SSAA > 1 (skeleton.cpp:336-361): SSAA^2 sub-rays per pixel, focal = SCREEN_WIDTH * SSAA, the sum
+    divided by SSAA (not SSAA^2, as the reference does)."""
+    kw = dict(photon_number=300, bounces=1, screen_width=96, screen_height=80, ssaa=ssaa)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        ctx.build_tree()
+        frames = {c: ctx.draw(cull=c).astype(np.float64) for c in ("scan", "lbvh", "bins")}
+        part = ctx.draw(8, 16, 40, 24, cull="bins").astype(np.float64)
+    tri, _ = orc.load_test_model()
+    ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
+                                   segs, lo, hi, 0, 0, 96, 80)
+    assert cnt["rays"] == 96 * 80 * ssaa * ssaa and ref.max() > 0.1
+    for name, img in frames.items():
+        err = np.abs(img - ref)
+        assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), (name, err.max())
+        assert np.sqrt((err ** 2).mean()) <= 1e-4, name
+    np.testing.assert_allclose(part, frames["bins"][16:40, 8:48], rtol=1e-6, atol=1e-9)
