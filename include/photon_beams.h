@@ -226,6 +226,27 @@ int pb_quantise_argb(const float* rgb, int n_pixels, uint32_t* argb_out);
 int pb_enable_counters(pb_ctx* ctx, int on);
 int pb_counters(pb_ctx* ctx, pb_stats* out);
 
+/* ---- known-answer probes --------------------------------------------------------------------------
+ * One GPU lane per query through the very device functions the frame and photon kernels inline; host
+ * arrays in and out.  For tests against vectors made with the reference's own functions; not used by the
+ * render path.
+ *
+ * ClosestIntersection (Intersections.h:458-497) for n rays (start, dir as xyzw) against the scene of
+ * pb_set_scene: found flag, Intersection.position (xyzw), .distance, .index (zeros / -1 where not found). */
+int pb_probe_closest_intersection(pb_ctx* ctx, const float* start_xyzw, const float* dir_xyzw, int n,
+                                  uint8_t* found, float* pos_xyzw, float* dist, int32_t* index);
+/* HitBoundingBox (Intersections.h:81-143) for rays from (0,0,0) (every camera ray) against boxes given
+ * un-flipped (lo = min_b, hi = max_b of :85-86): hit flag and |hit - start| as BeamRadiance.h:429 forms it. */
+int pb_probe_hit_bounding_box(pb_ctx* ctx, const float* lo_xyz, const float* hi_xyz, const float* dir_xyzw, int n,
+                              uint8_t* hit, float* entry_distance);
+/* Pair i = (ray from (0,0,0) along dir[i], segs[i]) with its own gate box and no surface in the way.
+ * cyl_out12[i] = HitCylinder's (Intersections.h:307-456) return value, valid, tb_minus, tb_plus, tc_minus,
+ * tc_plus, entry_point, exit_point (zeros where the reference leaves them unset) in the exact operation
+ * order; integral[i], status[i] = value of Integral_721 (BeamRadiance.h:86-110; fast != 0: the default
+ * fast form) or Integral_73Het (:211-288) and 0 no hit / 1 hit without contribution / 2 contributed. */
+int pb_probe_pairs(pb_ctx* ctx, const pb_segment* segs, const float* dir_xyzw, int n, int mode, int fast,
+                   float* cyl_out12, double* integral, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

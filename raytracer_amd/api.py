@@ -242,6 +242,39 @@ class Context:
                "pb_extinction3d")
         return (mean, cnt, samp) if max_samples else (mean, cnt)
 
+    # ---- known-answer probes: one GPU lane per query through the kernels' own device functions ----
+    def probe_closest_intersection(self, start_xyzw, dir_xyzw):
+        a = np.ascontiguousarray(start_xyzw, np.float32).reshape(-1, 4)
+        d = np.ascontiguousarray(dir_xyzw, np.float32).reshape(-1, 4)
+        n = len(a)
+        found = np.zeros(n, np.uint8); pos = np.zeros((n, 4), np.float32)
+        dist = np.zeros(n, np.float32); idx = np.zeros(n, np.int32)
+        _check(self.L.pb_probe_closest_intersection(self.h, _fp(a), _fp(d), C.c_int(n), found.ctypes.data_as(C.c_void_p),
+                                                    _fp(pos), _fp(dist), idx.ctypes.data_as(C.c_void_p)),
+               "pb_probe_closest_intersection")
+        return found, pos, dist, idx
+
+    def probe_hit_bounding_box(self, lo_xyz, hi_xyz, dir_xyzw):
+        lo = np.ascontiguousarray(lo_xyz, np.float32).reshape(-1, 3)
+        hi = np.ascontiguousarray(hi_xyz, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dir_xyzw, np.float32).reshape(-1, 4)
+        n = len(lo)
+        hit = np.zeros(n, np.uint8); dist = np.zeros(n, np.float32)
+        _check(self.L.pb_probe_hit_bounding_box(self.h, _fp(lo), _fp(hi), _fp(d), C.c_int(n),
+                                                hit.ctypes.data_as(C.c_void_p), _fp(dist)), "pb_probe_hit_bounding_box")
+        return hit, dist
+
+    def probe_pairs(self, segs, dir_xyzw, mode=MODE_721, fast=False):
+        segs = np.ascontiguousarray(segs)
+        assert segs.dtype == SEGMENT_DTYPE
+        d = np.ascontiguousarray(dir_xyzw, np.float32).reshape(-1, 4)
+        n = len(segs)
+        cyl = np.zeros((n, 12), np.float32); val = np.zeros(n, np.float64); st = np.zeros(n, np.int32)
+        _check(self.L.pb_probe_pairs(self.h, segs.ctypes.data_as(C.c_void_p), _fp(d), C.c_int(n), C.c_int(mode),
+                                     C.c_int(1 if fast else 0), _fp(cyl), val.ctypes.data_as(C.c_void_p),
+                                     st.ctypes.data_as(C.c_void_p)), "pb_probe_pairs")
+        return cyl, val, st
+
     def upload_segments(self, segs, root_lo, root_hi):
         """The segment set BuildTree would hold (CastPhotons.h:83, :808) and CastPhotonBeams' root box."""
         segs = np.ascontiguousarray(segs)

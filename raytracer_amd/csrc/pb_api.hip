@@ -84,7 +84,7 @@ int ensure_workspace(pb_ctx* ctx, int groups, int chunks) {
     if (ctx->d_rays) PB_HIP(hipFree(ctx->d_rays));
     if (ctx->d_group_last) PB_HIP(hipFree(ctx->d_group_last));
     ctx->d_rays = nullptr; ctx->d_group_last = nullptr; ctx->ws_groups = 0;
-    PB_HIP(hipMalloc(&ctx->d_rays, sizeof(float) * 8 * 64 * (size_t)groups));
+    PB_HIP(hipMalloc(&ctx->d_rays, sizeof(float) * PB_RAY_WORDS * 64 * (size_t)groups));
     PB_HIP(hipMalloc(&ctx->d_group_last, sizeof(int) * (size_t)groups));
     ctx->ws_groups = groups;
   }

@@ -101,7 +101,7 @@ struct RenderParams {
   float* out;              // out_h * out_w * 3
   unsigned long long* counters;  // 8 words or nullptr
   // workspace of one frame (see pb_render.hip)
-  float* rays;              // [groups][8][64]: l.xyz, dn.xyz, maxd, 0
+  float* rays;              // [groups][PB_RAY_WORDS][64]: l.xyz, dn.xyz, maxd, 0, d1.xyz, 0
   int* group_last;          // [groups]: last chunk of the group's list, -1 if none
   uint32_t* chunks;         // [chunk_capacity][PB_CHUNK_WORDS]: group, count, prev, 0, indices
   double* partials;         // [chunk_capacity][3][64]
@@ -133,6 +133,7 @@ struct RenderParams {
   int lbvh_n;
 };
 
+constexpr int PB_RAY_WORDS = 12;       // floats stored per camera ray
 constexpr int PB_CHUNK = 124;          // candidates per chunk
 constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 512 B
 constexpr int PB_EVAL_WAVES = 256 * 32;

@@ -12,289 +12,9 @@
 #include "pb_internal.h"
 #include "pb_geom.h"
 #include "pb_grid.h"
+#include "pb_pair.h"
 
 namespace {
-
-struct Ray {
-  V3 l;        // normalize(vec3(dir))              Intersections.h:313, BeamRadiance.h:88
-  V3 dn;       // xyz of normalize(vec4 dir) again  Intersections.h:91
-  float maxd;  // |limit.position - start|          BeamRadiance.h:426
-  bool active;
-};
-
-// HitBoundingBox (Intersections.h:81-143) for a ray from (0,0,0) followed by the
-// distance test of BeamRadiance.h:429-430.  lo/hi are min_b/max_b, cand/qflags
-// the origin-dependent part prepared per box.
-PB_DI bool box_gate(const float lo[3], const float hi[3], const float cand[3], uint32_t qflags, V3 dn, float maxd) {
-  if (qflags & 8u) return 0.0f <= maxd;   // origin inside: hit = start, distance 0
-  const float d[3] = {dn.x, dn.y, dn.z};
-  float dist[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) dist[i] = (d[i] != 0 && !((qflags >> i) & 1u)) ? (cand[i] / d[i]) : -1.0f;
-  int largest = 0;
-  float dl = dist[0];
-  if (dl < dist[1]) { largest = 1; dl = dist[1]; }
-  if (dl < dist[2]) { largest = 2; dl = dist[2]; }
-  if (dl < 0) return false;
-  float pos[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (largest != i) {
-      pos[i] = dl * d[i];                       // origin[i] + ... with origin 0
-      if (pos[i] < lo[i] || pos[i] > hi[i]) return false;
-    } else pos[i] = cand[i];
-  }
-  // |hit - start| as a vec4 length with w = 1 - 1 = 0
-  const float hd = pb_sqrt((pos[0] * pos[0] + pos[1] * pos[1]) + (pos[2] * pos[2] + 0.0f));
-  return hd <= maxd;
-}
-
-// Per-pixel set-up of DrawStandard, skeleton.cpp:342-350, then the root gate.
-PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
-  Ray r;
-  const float x_dir = sx - ((p.width * p.ssaa) / (float)2);
-  const float y_dir = sy - ((p.height * p.ssaa) / (float)2);
-  const V4 dir = normalize4(v4(x_dir, y_dir, p.focal, 1.0f));
-  const V4 start = v4(0, 0, 0, 1);
-  V4 pos = v4(0, 0, 0, 0);
-  float dist; int idx;
-  r.active = closest_intersection(p.tris, p.n_tri, start, dir, pos, dist, idx);
-  r.maxd = r.active ? length4(pos - start) : -1.0f;
-  r.l = normalize3(xyz(dir));
-  r.dn = xyz(normalize4(dir));
-  return r;
-}
-
-// CylIntersection (Intersections.h:29-40) of a valid hit.
-struct CylHit {
-  V3 entry, exit;
-  float tb_minus, tc_minus, tc_plus;
-};
-
-// HitCylinder (Intersections.h:307-456) with the per-segment frame prepared, then the segment's gate
-// box (BeamRadiance.h:426-430).  Returns 0 = no cylinder hit, 1 = discriminant >= 0 but nothing to
-// integrate, 2 = valid intersection behind an open gate (h filled in).
-PB_DI int hit_cylinder_exact(const SegFrame& f, const Ray& r, CylHit& h) {
-  const V3 l = r.l;
-  const float dpx = f.Rinv[0] * l.x + f.Rinv[3] * l.y + f.Rinv[6] * l.z;
-  const float dpz = f.Rinv[2] * l.x + f.Rinv[5] * l.y + f.Rinv[8] * l.z;
-  const float a = dpx * dpx + dpz * dpz;
-  const float b = f.ox2 * dpx + f.oz2 * dpz;
-  const float b24ac = b * b - a * f.c4;
-  if (b24ac < 0) return 0;
-  const float sq = pb_sqrt(b24ac);
-  float t0 = (-b + sq) / (2 * a);
-  float t1 = (-b - sq) / (2 * a);
-  if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
-  const float dpy = f.Rinv[1] * l.x + f.Rinv[4] * l.y + f.Rinv[7] * l.z;
-  const float ox = f.ox, oy = f.oy, oz = f.oz;
-  const float y0 = oy + t0 * dpy;
-  const float y1 = oy + t1 * dpy;
-  float thf = 0.0f, ths = 0.0f;
-  bool have_second = false;
-  if (y0 < 0) {
-    if (y1 < 0) return 1;
-    thf = t0 + (t1 - t0) * y0 / (y0 - y1);
-    if (thf <= 0) return 1;
-    if (y1 <= 1) { ths = t1; have_second = true; }
-    else { float th2 = t1 + (t1 - t0) * (y1 - 1) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
-  } else if (y0 >= 0 && y0 <= 1) {
-    if (t0 <= 0) return 1;
-    thf = t0;
-    if (y1 >= 0) {
-      if (y1 <= 1) { ths = t1; have_second = true; }
-      else { float th2 = t1 + (t1 - t0) * (y1 - 1) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
-    } else { float th2 = t0 + (t1 - t0) * (y0) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
-  } else if (y0 > 1) {
-    if (y1 > 1) return 1;
-    thf = t0 + (t1 - t0) * (y0 - 1) / (y0 - y1);
-    if (thf <= 0) return 1;
-    if (y1 >= 0) { ths = t1; have_second = true; }
-    else { float th2 = t0 + (t1 - t0) * (y0) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
-  } else return 1;
-  if (!((t0 > 0) && (t1 > 0) && (t1 > t0))) return 1;
-  // the segment's gate box; the root gate was applied to the ray (maxd < 0 if it failed)
-  if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
-  const float fx = ox + dpx * thf, fy = oy + dpy * thf, fz = oz + dpz * thf;
-  // second_hit is unset in the reference when no branch assigned it; that never
-  // coincides with valid == true, (0,0,0) stands in as in the CPU restatement
-  const float sx = have_second ? ox + dpx * ths : 0.0f;
-  const float sy = have_second ? oy + dpy * ths : 0.0f;
-  const float sz = have_second ? oz + dpz * ths : 0.0f;
-  const float tb_a = f.tb0 + (fy / f.Sinv);
-  const float tb_b = f.tb0 + (sy / f.Sinv);
-  const float tb_minus = fminf(tb_a, tb_b);
-  const float ux = fx - ox, uy = fy - oy, uz = fz - oz;
-  const float ex = (f.R[0] * ux + f.R[3] * uy + f.R[6] * uz) / f.Sinv;
-  const float ey = (f.R[1] * ux + f.R[4] * uy + f.R[7] * uz) / f.Sinv;
-  const float ez = (f.R[2] * ux + f.R[5] * uy + f.R[8] * uz) / f.Sinv;
-  const float wx = sx - ox, wy = sy - oy, wz = sz - oz;
-  const float qx = (f.R[0] * wx + f.R[3] * wy + f.R[6] * wz) / f.Sinv;
-  const float qy = (f.R[1] * wx + f.R[4] * wy + f.R[7] * wz) / f.Sinv;
-  const float qz = (f.R[2] * wx + f.R[5] * wy + f.R[8] * wz) / f.Sinv;
-  h.entry = v3(ex, ey, ez);
-  h.exit = v3(qx, qy, qz);
-  h.tb_minus = tb_minus;
-  h.tc_minus = pb_sqrt(ex * ex + ey * ey + ez * ez);
-  h.tc_plus = pb_sqrt(qx * qx + qy * qy + qz * qz);
-  return 2;
-}
-
-// Integral_721 (BeamRadiance.h:86-110) on a valid hit: float products and float exp, widened for the
-// quotient.  Same return convention as hit_cylinder_exact.
-PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, double& integral_out) {
-  CylHit h;
-  const int res = hit_cylinder_exact(f, r, h);
-  if (res != 2) return res;
-  const V3 l = r.l;
-  const float cos_theta = f.bdir[0] * (-l.x) + f.bdir[1] * (-l.y) + f.bdir[2] * (-l.z);
-  const float cm1 = fabsf(cos_theta) - 1;
-  const float num = expf(-extinction * (h.tc_minus - h.tc_plus) * cm1) - 1;
-  const float den = expf(extinction * (h.tc_minus + h.tb_minus)) * extinction * cm1;
-  integral_out = (double)num / (double)den;
-  return 2;
-}
-
-// Integral_73Het (BeamRadiance.h:211-288): closest approach of the beam axis and the view ray in
-// double, the beam's extinction interpolated within the segment, the view ray's extinction by a
-// walk through the grid from the camera to the point of closest approach.
-struct D3v { double x, y, z; };
-PB_DI D3v d3(V3 v) { D3v r; r.x = (double)v.x; r.y = (double)v.y; r.z = (double)v.z; return r; }
-PB_DI D3v operator+(D3v a, D3v b) { D3v r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; return r; }
-PB_DI D3v operator-(D3v a, D3v b) { D3v r; r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z; return r; }
-PB_DI D3v operator*(double s, D3v a) { D3v r; r.x = s * a.x; r.y = s * a.y; r.z = s * a.z; return r; }
-PB_DI D3v operator*(D3v a, double s) { D3v r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; return r; }
-PB_DI double ddot(D3v a, D3v b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-PB_DI double dlength(D3v a) { return __builtin_sqrt(ddot(a, a)); }
-PB_DI D3v dnormalize(D3v a) { return a * (1.0 / __builtin_sqrt(ddot(a, a))); }
-
-PB_DI double integral_73het(const GridView& grid, V3 seg_start, V3 seg_end, const HetFrame& hf, const CylHit& h,
-                            const Ray& r, float extinction_c, float scattering_c) {
-  const D3v a = d3(seg_start), c = d3(h.exit);
-  const D3v b = d3(seg_end), d = d3(h.entry);
-  const D3v ab = dnormalize(b - a);
-  const D3v cd = dnormalize(d - c);
-  const double u_dot_u = ddot(ab, ab), u_dot_v = ddot(ab, cd), v_dot_v = ddot(cd, cd);
-  const double u_dot_w = ddot(ab, a - c), v_dot_w = ddot(cd, a - c);
-  const double denominator = u_dot_u * v_dot_v - u_dot_v * u_dot_v;
-  if (!((denominator != 0) && (u_dot_u != 0) && (v_dot_v != 0))) return 0.0;
-  const double t_ab = (u_dot_v * v_dot_w - v_dot_v * u_dot_w) / denominator;
-  const double t_cd = (u_dot_u * v_dot_w - u_dot_v * u_dot_w) / denominator;
-  const D3v point_beam = a + (t_ab * ab);
-  const D3v point_view = c + (t_cd * cd);
-  const D3v os = d3(v3(hf.os[0], hf.os[1], hf.os[2]));
-  const double view_distance = dlength(point_view);
-  const double beam_distance = dlength(point_beam - os);
-  const double a_os = dlength(a - os), b_os = dlength(b - os);
-  const bool bound1 = (view_distance >= dlength(d)) && (view_distance <= dlength(c));
-  const bool bound2 = (beam_distance >= a_os) && (beam_distance <= b_os);
-  if (!(bound1 && bound2)) return 0.0;
-  const double t_bc = beam_distance;
-  const double t_cb = view_distance;
-  const float proportion = (float)((t_bc - a_os) / (b_os - a_os));
-  const float additional = hf.s_ext + ((hf.e_ext - hf.s_ext) * proportion);
-  const float beam_extinction = hf.c_ext + ((additional - hf.c_ext) / (hf.seg_id + 1));
-  // vec4(0,0,0,1) + dir * (float) t_cb, dir the normalised vec4 of DrawHet (skeleton.cpp:383-387)
-  const float reach = (float)t_cb;
-  const V3 view_end = v3(0.0f + (r.dn.x * reach), 0.0f + (r.dn.y * reach), 0.0f + (r.dn.z * reach));
-  const float view_extinction = extinction3d_mean(grid, v3(0, 0, 0), view_end);
-  const double transmitted = exp(-(double)beam_extinction * t_bc) * exp(-(double)view_extinction * t_cb);
-  const float scattering = (beam_extinction / extinction_c) * scattering_c;
-  if (transmitted < 1e-6) return 0.0;
-  const double cos_theta = ddot(ab, cd);
-  const double sin_theta = __builtin_sqrt(1 - cos_theta * cos_theta);
-  const double rad = (double)(scattering / hf.radius);
-  return transmitted * rad / sin_theta;
-}
-
-// One (ray, segment) pair of BVHBeamRadianceHet (BeamRadiance.h:378-398).
-PB_DI int eval_pair_73het(const SegFrame& f, const HetFrame& hf, V3 seg_start, V3 seg_end, const GridView& grid,
-                          const Ray& r, float extinction_c, float scattering_c, double& integral_out) {
-  CylHit h;
-  const int res = hit_cylinder_exact(f, r, h);
-  if (res != 2) return res;
-  integral_out = integral_73het(grid, seg_start, seg_end, hf, h, r, extinction_c, scattering_c);
-  return 2;
-}
-
-// The same pair evaluation with the arithmetic the estimate is continuous in relaxed to what the
-// hardware does fastest; the radiance differs from the exact-order form above by the reference's own
-// float rounding noise (about 1e-5 relative per pixel), far inside the stated tolerance.
-//  * fused multiply-adds, v_rcp/v_sqrt instead of IEEE divide/sqrt;
-//  * entry/exit distances from the ray parameter: the rotation back to world space and its length
-//    (Intersections.h:443-450) return |l * th / S_inv| = th * |end - start| for a camera at the origin;
-//  * cos(theta) = -dot(beam_dir, l) is the y component of R_inv * l;
-//  * exp(x) - 1 by its series where |x| is small (the reference's float exp loses 4 digits there);
-//  * the gate: a segment whose gate box contains its cylinder (qflags bit 4) passes whenever the
-//    cylinder exit lies in front of the surface, since the box entry comes before it; otherwise, and for
-//    every other segment, the exact HitBoundingBox gate runs.
-PB_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
-template <bool CHECK>
-PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong) {
-  const V3 l = r.l;
-  const float dpx = __builtin_fmaf(f.Rinv[6], l.z, __builtin_fmaf(f.Rinv[3], l.y, f.Rinv[0] * l.x));
-  const float dpz = __builtin_fmaf(f.Rinv[8], l.z, __builtin_fmaf(f.Rinv[5], l.y, f.Rinv[2] * l.x));
-  const float a = __builtin_fmaf(dpx, dpx, dpz * dpz);
-  const float b = __builtin_fmaf(f.ox2, dpx, f.oz2 * dpz);
-  const float b24ac = __builtin_fmaf(b, b, -(a * f.c4));
-  if (b24ac < 0) return 0;
-  const float sq = __builtin_amdgcn_sqrtf(b24ac);
-  const float inv2a = fast_rcp(a + a);
-  const float t0 = (-b - sq) * inv2a;     // a > 0: already ordered, t0 <= t1
-  const float t1 = (-b + sq) * inv2a;
-  const float dpy = __builtin_fmaf(f.Rinv[7], l.z, __builtin_fmaf(f.Rinv[4], l.y, f.Rinv[1] * l.x));
-  const float oy = f.oy;
-  const float y0 = __builtin_fmaf(t0, dpy, oy);
-  const float y1 = __builtin_fmaf(t1, dpy, oy);
-  float thf, ths = 0.0f;
-  bool have_second = false;
-  const float dt = t1 - t0;
-  if (y0 >= 0 && y0 <= 1) {
-    if (t0 <= 0) return 1;
-    thf = t0;
-    if (y1 >= 0 && y1 <= 1) { ths = t1; have_second = true; }
-    else {
-      const float q = fast_rcp(y0 - y1);
-      const float th2 = (y1 > 1) ? __builtin_fmaf(dt * (y1 - 1), q, t1) : __builtin_fmaf(dt * y0, q, t0);
-      if (th2 > 0) { ths = th2; have_second = true; }
-    }
-  } else if (y0 < 0) {
-    if (y1 < 0) return 1;
-    const float q = fast_rcp(y0 - y1);
-    thf = __builtin_fmaf(dt * y0, q, t0);
-    if (thf <= 0) return 1;
-    if (y1 <= 1) { ths = t1; have_second = true; }
-    else { const float th2 = __builtin_fmaf(dt * (y1 - 1), q, t1); if (th2 > 0) { ths = th2; have_second = true; } }
-  } else if (y0 > 1) {
-    if (y1 > 1) return 1;
-    const float q = fast_rcp(y0 - y1);
-    thf = __builtin_fmaf(dt * (y0 - 1), q, t0);
-    if (thf <= 0) return 1;
-    if (y1 >= 0) { ths = t1; have_second = true; }
-    else { const float th2 = __builtin_fmaf(dt * y0, q, t0); if (th2 > 0) { ths = th2; have_second = true; } }
-  } else return 1;
-  if (!((t0 > 0) && (t1 > t0))) return 1;
-  const float tc_minus = thf * f.len;
-  const float tc_plus = have_second ? ths * f.len : 0.0f;
-  const bool sure = (f.qflags & 16u) && have_second && (fmaxf(tc_minus, tc_plus) < r.maxd * 0.99999f);
-  if (!sure) {
-    if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
-  } else if (CHECK) {
-    if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) shortcut_wrong++;
-  }
-  const float fy = __builtin_fmaf(dpy, thf, oy);
-  const float sy = have_second ? __builtin_fmaf(dpy, ths, oy) : 0.0f;
-  const float tb_minus = f.tb0 + fminf(fy, sy) * f.len;
-  const float cm1 = fabsf(dpy) - 1.0f;
-  const float x = -extinction * (tc_minus - tc_plus) * cm1;
-  float num;
-  if (fabsf(x) < 0.02f) num = x * __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
-  else num = expf(x) - 1.0f;
-  const float den = __expf(extinction * (tc_minus + tb_minus)) * extinction * cm1;
-  integral_out = (double)(num * fast_rcp(den));
-  return 2;
-}
 
 // Conservative test: can the capsule (a, b, radius) touch the pyramid of the tile?
 // pl[k] are the four inward unit normals of the side planes (through the origin).
@@ -424,10 +144,11 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   const bool hit_scene = r.active;
   r.active = r.active && box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd);
   if (!r.active) r.maxd = -1.0f;     // every gate fails for this lane
-  float* rr = p.rays + (size_t)group * 8 * 64;
+  float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
   rr[0 * 64 + lane] = r.l.x; rr[1 * 64 + lane] = r.l.y; rr[2 * 64 + lane] = r.l.z;
   rr[3 * 64 + lane] = r.dn.x; rr[4 * 64 + lane] = r.dn.y; rr[5 * 64 + lane] = r.dn.z;
   rr[6 * 64 + lane] = r.maxd; rr[7 * 64 + lane] = 0.0f;
+  rr[8 * 64 + lane] = r.d1.x; rr[9 * 64 + lane] = r.d1.y; rr[10 * 64 + lane] = r.d1.z; rr[11 * 64 + lane] = 0.0f;
 
   ChunkWriter w;
   w.buf = buf; w.count = 0; w.prev = -1; w.group = group;
@@ -548,11 +269,12 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
     const PB_CONST_AS uint32_t* ch = pb_uniform(p.chunks + (size_t)c * PB_CHUNK_WORDS);
     const int group = (int)ch[0];
     const int n = (int)ch[1];
-    const float* rr = p.rays + (size_t)group * 8 * 64;
+    const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
     Ray r;
     r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
     r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
     r.maxd = rr[6 * 64 + lane];
+    r.d1 = (MODE == PB_MODE_73HET) ? v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]) : r.dn;
     r.active = r.maxd >= 0.0f;
     double acc[3] = {0.0, 0.0, 0.0};
     for (int k = 0; k < n; ++k) {
@@ -651,10 +373,11 @@ __global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
   const bool hit_scene = r.active;
   r.active = r.active && box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd);
   if (!r.active) r.maxd = -1.0f;
-  float* rr = p.rays + (size_t)group * 8 * 64;
+  float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
   rr[0 * 64 + lane] = r.l.x; rr[1 * 64 + lane] = r.l.y; rr[2 * 64 + lane] = r.l.z;
   rr[3 * 64 + lane] = r.dn.x; rr[4 * 64 + lane] = r.dn.y; rr[5 * 64 + lane] = r.dn.z;
   rr[6 * 64 + lane] = r.maxd; rr[7 * 64 + lane] = 0.0f;
+  rr[8 * 64 + lane] = r.d1.x; rr[9 * 64 + lane] = r.d1.y; rr[10 * 64 + lane] = r.d1.z; rr[11 * 64 + lane] = 0.0f;
   const bool any = __ballot(r.active) != 0ull;
   if (lane == 0) p.group_last[group] = any ? 0 : -1;
   if (COUNT) {
@@ -1003,11 +726,12 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
     const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
     V3 pl[4];
     tile_planes(p, tx, tk, pl);
-    const float* rr = p.rays + (size_t)group * 8 * 64;
+    const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
     Ray r;
     r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
     r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
     r.maxd = rr[6 * 64 + lane];
+    r.d1 = (MODE == PB_MODE_73HET) ? v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]) : r.dn;
     r.active = r.maxd >= 0.0f;
     unsigned long long ai[3] = {0ull, 0ull, 0ull};
     uint32_t nc = 0;

@@ -142,12 +142,56 @@ def test_het_render_matches_oracle(pb):
     assert len(segs) > 5000 and ref.max() > 0.05 and cnt["valid_hits"] > 5000
     got = scan[0::2, 1::2][:128, :128]
     err = np.abs(got - ref)
-    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), err.max()
-    assert np.sqrt((err ** 2).mean()) <= 1e-4
+    # stated bar: 2e-3 max(1, |ref|) and RMSE 1e-4; this estimator keeps the reference's operation order
+    # throughout, so the frame agrees to the float32 rounding of the output
+    assert (err <= 1e-6 * np.maximum(1.0, np.abs(ref))).all(), err.max()
+    assert np.sqrt((err ** 2).mean()) <= 1e-7
     # the three candidate searches give the same frame (bins: fixed-point sums, quantum 2^-40 per term)
     np.testing.assert_allclose(lbvh, scan, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(bins, scan, rtol=1e-5, atol=1e-7)
     assert np.array_equal(bins.astype(np.float32), bins2)
     assert c_scan["valid_hits"] > 4 * cnt["valid_hits"] * 0.9   # full frame vs every 4th pixel
     q_ref = orc.put_pixels(ref); q_got = orc.put_pixels(got)
-    assert (q_ref == q_got).mean() > 0.999
+    assert np.array_equal(q_ref, q_got)
+
+
+def test_integral_73het_per_pair(pb):
+    """Integral_73Het pair by pair: rays from the camera aimed at points near the axis of oracle-made
+    heterogeneous segments; the GPU's cylinder record must equal the oracle's bit for bit and the integral
+    to 1e-9 relative (double arithmetic in the same order; device and host exp differ in the last bit)."""
+    octl = het_control(orc, photon_number=300, bounces=1)
+    o = orc.Oracle(octl)
+    sigma, side = o.make_grid()
+    o.cast_photon_beams(); o.bound_photon_beams()
+    items = o.export_segments(tree=False)
+    rng = np.random.default_rng(11)
+    pick = items[rng.integers(0, len(items), 3000)].copy()
+    pick["cull_lo"] = -10.0; pick["cull_hi"] = 10.0
+    u = rng.uniform(0.05, 0.95, (len(pick), 1)).astype(np.float32)
+    target = pick["start"] + u * (pick["end"] - pick["start"]) + rng.normal(scale=0.008, size=(len(pick), 3)).astype(np.float32)
+    dirs = np.ones((len(pick), 4), np.float32)
+    dirs[:, :3] = target
+    dirs = (dirs / np.sqrt((dirs * dirs).sum(1, keepdims=True))).astype(np.float32)
+    with pb.Context(het_control(pb)) as ctx:
+        ctx.set_scene()
+        ctx.set_grid(sigma, side)
+        cyl, val, st = ctx.probe_pairs(pick, dirs, mode=pb.MODE_73HET)
+    start = np.array([0, 0, 0, 1], np.float32)
+    n_valid = n_close = n_pos = 0
+    for i in range(len(pick)):
+        s0 = np.append(pick["start"][i], 1).astype(np.float32); s1 = np.append(pick["end"][i], 1).astype(np.float32)
+        so = np.append(pick["orig_start"][i], 1).astype(np.float32)
+        want = orc.hit_cylinder(start, dirs[i], s0, s1, so, float(pick["radius"][i]))
+        assert np.array_equal(cyl[i], want), i
+        if want[1] != 1:
+            assert st[i] != 2
+            continue
+        n_valid += 1
+        ref = orc.integral_73het(sigma, side, pick[i:i + 1], want[6:9], want[9:12], 0.04, 0.005, dirs[i])
+        n_pos += ref > 0
+        if abs(val[i] - ref) <= 1e-9 * abs(ref) + 1e-15:
+            n_close += 1
+        else:
+            assert abs(val[i] - ref) <= 0.05 * abs(ref) + 1e-6, (i, val[i], ref)
+    assert n_valid > 1000 and n_pos > 200
+    assert n_close >= 0.999 * n_valid, (n_close, n_valid)
