@@ -70,6 +70,16 @@ def cpu_baseline(args, control_kwargs, segs, root_lo, root_hi, grid=None):
             "n_valid_per_ray": cnt["valid_hits"] / max(cnt["rays"], 1)}
 
 
+def measured_traffic(workload, cull):
+    """HBM bytes per frame from the committed PMC passes (rocprofv3 cannot run inside this process)."""
+    path = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{workload}.json")
+    try:
+        d = json.load(open(path))
+        return float(d["traffic_bytes"]) if d.get("cull") == cull else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,11 +210,14 @@ def main():
                        "rays_per_frame": rays, "segments": n_segs, "cull": cull,
                        "parallelism": f"row-strips x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS,
+                         "traffic": measured_traffic(args.workload, cull) if world == 1 else None,
                          "kernel": "frame = ray_setup + bin/cull + eval + finalize kernels", "kernel_ms": kernel_ms,
                          "flop_per_ray": w_ray, "n_cull_per_ray": n_cull, "n_valid_per_ray": n_valid,
                          "note": "FP32 vector-ALU bound (no MFMA, working set in L2); achieved = algorithmic "
-                                 "flop per ray x rays per launch / measured launch time"},
+                                 "flop per ray x rays per launch / measured launch time; traffic = HBM bytes per "
+                                 "frame from separate rocprofv3 PMC passes (profiles/r01_hbm_traffic_*.json), "
+                                 "mostly the pixel atomics, which execute at the memory side"},
             "pair_queries_per_s": rays * n_segs * args.steps / dt,
             "frame_ok": frame_ok,
             "per_ray": {k: cnt[k] / rays for k in ("candidates", "cyl_hits", "valid_hits", "gate_passes")},
