@@ -133,7 +133,7 @@ int ensure_bin_workspace(pb_ctx* ctx, int tiles, int bin_cap, int item_cap, size
 int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long long key[6], hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   const int groups = tiles * p.ssaa * p.ssaa;
-  const size_t px = (size_t)p.out_w * p.out_h;
+  const size_t px = (size_t)tiles * 64;      // pixel sums are stored per tile
   bool verified = std::memcmp(key, ctx->ws_key, sizeof(unsigned long long) * 6) == 0;
   int want_bins = ctx->ws_bin_cap, want_items = ctx->ws_item_cap;
   if (!verified) {

@@ -45,6 +45,37 @@ PB_DI bool box_gate(const float lo[3], const float hi[3], const float cand[3], u
   return hd <= maxd;
 }
 
+// The same decision from reciprocals: 1 = passes, 0 = fails, 2 = within 1e-5 (relative) of the distance
+// threshold or of a box face, where only the exact-order form above may decide.
+PB_DI int box_gate_quick(const float lo[3], const float hi[3], const float cand[3], uint32_t qflags, V3 dn, float maxd) {
+  if (qflags & 8u) return (0.0f <= maxd) ? 1 : 0;
+  const float d[3] = {dn.x, dn.y, dn.z};
+  float dist[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dist[i] = (d[i] != 0 && !((qflags >> i) & 1u)) ? cand[i] * __builtin_amdgcn_rcpf(d[i]) : -1.0f;
+  const float dl = fmaxf(dist[0], fmaxf(dist[1], dist[2]));
+  const float tol = 1e-5f * (1.0f + fabsf(dl));
+  if (dl < -tol) return 0;
+  if (dl < tol) return 2;
+  // two candidate planes at nearly the same distance: which axis counts as the largest is the exact form's call
+  const int near = (dist[0] > dl - tol) + (dist[1] > dl - tol) + (dist[2] > dl - tol);
+  if (near > 1) return 2;
+  bool inside = true, clear = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (dist[i] > dl - tol) continue;           // the entry face itself
+    const float p = dl * d[i];
+    inside = inside && (p >= lo[i] - tol) && (p <= hi[i] + tol);
+    clear = clear && (p >= lo[i] + tol) && (p <= hi[i] - tol);
+  }
+  if (!inside) return 0;
+  if (!clear) return 2;
+  // |hit| = dl |dn| with |dn| = 1 to a few ulp
+  if (dl < maxd * 0.99999f) return 1;
+  if (dl > maxd * 1.00001f) return 0;
+  return 2;
+}
+
 // Per-pixel set-up of DrawStandard, skeleton.cpp:342-350, then the root gate.
 PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
   Ray r;
@@ -222,12 +253,18 @@ PB_DI int eval_pair_73het(const SegFrame& f, const HetFrame& hf, V3 seg_start, V
 // hardware does fastest; the radiance differs from the exact-order form above by the reference's own
 // float rounding noise (about 1e-5 relative per pixel), far inside the stated tolerance.
 //  * fused multiply-adds, v_rcp/v_sqrt instead of IEEE divide/sqrt;
+//  * validity first: a contributing pair needs 0 < t0 < t1 (Intersections.h:437), and then every cap
+//    crossing lies in [t0, t1], so the th <= 0 tests of the y-cases (:366-432) cannot fire;
+//  * the y-cases without branches: the hit points' y are y0, y1 clamped to [0, 1], and the ray parameter
+//    where y reaches a cap is t0 + (t1 - t0) (y0 - cap) / (y0 - y1), the formula of all four cap branches;
 //  * entry/exit distances from the ray parameter: the rotation back to world space and its length
 //    (Intersections.h:443-450) return |l * th / S_inv| = th * |end - start| for a camera at the origin;
 //  * cos(theta) = -dot(beam_dir, l) is the y component of R_inv * l;
-//  * exp(x) - 1 by its series where |x| is small (the reference's float exp loses 4 digits there);
-//  * the gate: a segment whose gate box contains its cylinder (qflags bit 4) passes whenever the
-//    cylinder exit lies in front of the surface, since the box entry comes before it; otherwise, and for
+//  * Integral_721 = (exp(x) - 1) / (exp(E) sigma_t (c - 1)) with x = sigma_t (tc+ - tc-) (c - 1) is evaluated as
+//    (tc+ - tc-) * ((exp(x) - 1) / x) * exp(-E): no division, no 0/0 at c = 1, and (exp(x) - 1) / x by its
+//    series where |x| is small (the reference's float exp loses 4 digits there);
+//  * the gate: a segment whose gate box contains its cylinder (qflags bit 4) passes whenever the ray
+//    enters the cylinder in front of the surface, since it enters the box no later; otherwise, and for
 //    every other segment, the exact HitBoundingBox gate runs.
 PB_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -244,56 +281,39 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
   const float inv2a = fast_rcp(a + a);
   const float t0 = (-b - sq) * inv2a;     // a > 0: already ordered, t0 <= t1
   const float t1 = (-b + sq) * inv2a;
-  const float dpy = __builtin_fmaf(f.Rinv[7], l.z, __builtin_fmaf(f.Rinv[4], l.y, f.Rinv[1] * l.x));
-  const float oy = f.oy;
-  const float y0 = __builtin_fmaf(t0, dpy, oy);
-  const float y1 = __builtin_fmaf(t1, dpy, oy);
-  float thf, ths = 0.0f;
-  bool have_second = false;
-  const float dt = t1 - t0;
-  if (y0 >= 0 && y0 <= 1) {
-    if (t0 <= 0) return 1;
-    thf = t0;
-    if (y1 >= 0 && y1 <= 1) { ths = t1; have_second = true; }
-    else {
-      const float q = fast_rcp(y0 - y1);
-      const float th2 = (y1 > 1) ? __builtin_fmaf(dt * (y1 - 1), q, t1) : __builtin_fmaf(dt * y0, q, t0);
-      if (th2 > 0) { ths = th2; have_second = true; }
-    }
-  } else if (y0 < 0) {
-    if (y1 < 0) return 1;
-    const float q = fast_rcp(y0 - y1);
-    thf = __builtin_fmaf(dt * y0, q, t0);
-    if (thf <= 0) return 1;
-    if (y1 <= 1) { ths = t1; have_second = true; }
-    else { const float th2 = __builtin_fmaf(dt * (y1 - 1), q, t1); if (th2 > 0) { ths = th2; have_second = true; } }
-  } else if (y0 > 1) {
-    if (y1 > 1) return 1;
-    const float q = fast_rcp(y0 - y1);
-    thf = __builtin_fmaf(dt * (y0 - 1), q, t0);
-    if (thf <= 0) return 1;
-    if (y1 >= 0) { ths = t1; have_second = true; }
-    else { const float th2 = __builtin_fmaf(dt * y0, q, t0); if (th2 > 0) { ths = th2; have_second = true; } }
-  } else return 1;
   if (!((t0 > 0) && (t1 > t0))) return 1;
+  const float dpy = __builtin_fmaf(f.Rinv[7], l.z, __builtin_fmaf(f.Rinv[4], l.y, f.Rinv[1] * l.x));
+  const float y0 = __builtin_fmaf(t0, dpy, f.oy);
+  const float y1 = __builtin_fmaf(t1, dpy, f.oy);
+  if (fmaxf(y0, y1) < 0.0f || fminf(y0, y1) > 1.0f) return 1;      // passes below or above both caps
+  const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);         // y of the entry and exit points
+  const float sy = __builtin_amdgcn_fmed3f(y1, 0.0f, 1.0f);
+  const float dt = t1 - t0;
+  const float q = dt * fast_rcp(y0 - y1);                           // unused (selected away) where y0 == y1
+  const float thf = (fy == y0) ? t0 : __builtin_fmaf(y0 - fy, q, t0);
+  const float ths = (sy == y1) ? t1 : __builtin_fmaf(y0 - sy, q, t0);
   const float tc_minus = thf * f.len;
-  const float tc_plus = have_second ? ths * f.len : 0.0f;
-  const bool sure = (f.qflags & 16u) && have_second && (fmaxf(tc_minus, tc_plus) < r.maxd * 0.99999f);
+  const float tc_plus = ths * f.len;
+  const bool sure = (f.qflags & 16u) && (tc_minus < r.maxd * 0.99999f);
   if (!sure) {
-    if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
+    // entered behind the surface (or a box that does not hold its cylinder): the box decides.  Its entry
+    // distance first with v_rcp; the exact-order gate only where that lands within 1e-5 of a threshold.
+    const int quick = box_gate_quick(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd);
+    if (quick == 0) return 1;
+    if (quick == 2 && !box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
   } else if (CHECK) {
     if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) shortcut_wrong++;
   }
-  const float fy = __builtin_fmaf(dpy, thf, oy);
-  const float sy = have_second ? __builtin_fmaf(dpy, ths, oy) : 0.0f;
-  const float tb_minus = f.tb0 + fminf(fy, sy) * f.len;
+  const float chord = tc_plus - tc_minus;
+  const float tb_minus = __builtin_fmaf(fminf(fy, sy), f.len, f.tb0);
   const float cm1 = fabsf(dpy) - 1.0f;
-  const float x = -extinction * (tc_minus - tc_plus) * cm1;
-  float num;
-  if (fabsf(x) < 0.02f) num = x * __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
-  else num = expf(x) - 1.0f;
-  const float den = __expf(extinction * (tc_minus + tb_minus)) * extinction * cm1;
-  integral_out = (double)(num * fast_rcp(den));
+  const float x = extinction * chord * cm1;
+  float phi;                                                        // (exp(x) - 1) / x
+  if (__builtin_expect(fabsf(x) < 0.02f, 1))
+    phi = __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
+  else phi = (__expf(x) - 1.0f) * fast_rcp(x);
+  const float fall = __expf(-extinction * (tc_minus + tb_minus));
+  integral_out = (double)(chord * phi * fall);
   return 2;
 }
 

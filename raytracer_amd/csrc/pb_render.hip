@@ -127,17 +127,6 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
   const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + ly;
   const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
 
-  if (p.fused_queue) {
-    // this launch also clears what the frame accumulates into: the pixel sums and the bin counters
-    if (sub == 0 && ox < p.out_w && oy < p.out_h) {
-      unsigned long long* a = p.accum + ((size_t)oy * p.out_w + ox) * 3;
-      a[0] = 0ull; a[1] = 0ull; a[2] = 0ull;
-    }
-    if (group == 0) {
-      const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
-      for (int i = lane; i < n_macro; i += 64) { p.sub_count[i] = 0u; p.sub_fill[i] = 0u; }
-    }
-  }
   Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
   r.active = r.active && in_image;
   // the root gate is a property of the ray alone (BeamRadiance.h:426-430 at the tree root)
@@ -359,9 +348,9 @@ __global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
   const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
   if (p.fused_queue) {
     // this launch also clears what the frame accumulates into: the pixel sums and the bin counters
-    if (sub == 0 && ox < p.out_w && oy < p.out_h) {
-      unsigned long long* a = p.accum + ((size_t)oy * p.out_w + ox) * 3;
-      a[0] = 0ull; a[1] = 0ull; a[2] = 0ull;
+    if (sub == 0) {
+      unsigned long long* a = p.accum + (size_t)tile * 3 * 64 + lane;   // [tile][channel][lane]
+      a[0] = 0ull; a[64] = 0ull; a[128] = 0ull;
     }
     if (group == 0) {
       const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
@@ -784,12 +773,13 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
       __syncthreads();   // surv is rewritten by the next item
     }
     if (nc && !(p.ablate & 1)) {
-      const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
-      unsigned long long* dst = p.accum + ((size_t)oy * p.out_w + ox) * 3;   // active lanes are inside the image
+      // sums are kept per tile, [tile][channel][lane]: one atomic instruction covers 512 contiguous bytes
+      // (the adds run at the memory side in 64-byte requests; pixel-major rows cost three times as many)
+      unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
       const unsigned long long bias = (unsigned long long)nc * magic_bits;
       atomicAdd(&dst[0], ai[0] - bias);
-      atomicAdd(&dst[1], ai[1] - bias);
-      atomicAdd(&dst[2], ai[2] - bias);
+      atomicAdd(&dst[64], ai[1] - bias);
+      atomicAdd(&dst[128], ai[2] - bias);
     }
   }
   if (COUNT) {
@@ -823,8 +813,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
   const size_t n = (size_t)p.out_w * p.out_h;
   if (i >= n) return;
   const double inv = PB_FIX_SCALE / (double)p.ssaa;      // skeleton.cpp:361: current / (double) SSAA
+  const int ox = (int)(i % (size_t)p.out_w), oy = (int)(i / (size_t)p.out_w);
+  const size_t tile = (size_t)(oy >> 3) * p.tiles_x + (ox >> 3);
+  const unsigned long long* a = p.accum + tile * 3 * 64 + ((oy & 7) * 8 + (ox & 7));
   for (int k = 0; k < 3; ++k) {
-    const long long v = (long long)p.accum[i * 3 + k];
+    const long long v = (long long)a[k * 64];
     p.out[i * 3 + k] = (float)((double)v * inv);
   }
 }
