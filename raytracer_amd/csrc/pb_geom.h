@@ -4,13 +4,20 @@
 #include "pb_internal.h"
 
 // ClosestIntersection, Intersections.h:458-497, on prepared triangles.
+// screen_box (optional, rays from the camera at (0,0,0) only): per triangle the bounds of x/z and y/z over
+// its vertices, widened by 1e-3.  A ray outside them cannot satisfy the barycentric tests (they hold to a
+// few 1e-6), so the triangle is skipped without evaluating it; the result is unchanged.
 PB_DI bool closest_intersection(const TriPrep* __restrict__ tris, int n_tri, V4 start, V4 dir, V4& position,
-                                float& distance, int& index) {
+                                float& distance, int& index, const float4* __restrict__ screen_box = nullptr) {
   bool found = false;
   float best = 3.402823466e+38f;   // Intersections.h:57
   int best_i = -1;
   const float ndx = -dir.x, ndy = -dir.y, ndz = -dir.z;
   for (int i = 0; i < n_tri; ++i) {
+    if (screen_box) {
+      const float4 sb = screen_box[i];
+      if (dir.x < sb.x * dir.z || dir.x > sb.y * dir.z || dir.y < sb.z * dir.z || dir.y > sb.w * dir.z) continue;
+    }
     const TriPrep& T = tris[i];
     const float bx = start.x - T.v0[0], by = start.y - T.v0[1], bz = start.z - T.v0[2];
     const float e1x = T.e1[0], e1y = T.e1[1], e1z = T.e1[2];

@@ -82,6 +82,7 @@ struct GateBox {
 
 struct RenderParams {
   const TriPrep* tris;
+  const float4* tri_box;   // per triangle: bounds of x/z, y/z seen from the camera (lo, hi, lo, hi)
   int n_tri;
   const SegFrame* frames;
   const float4* capA;      // (start.xyz, radius)
@@ -166,7 +167,7 @@ struct pb_ctx {
   // scene
   float* d_tri_xyz = nullptr;
   float* d_matrix = nullptr;
-  TriPrep* d_tris = nullptr;
+  TriPrep* d_tris = nullptr;            // followed by n_tri float4 screen boxes
   int n_tri = 0;
   float matrix[16];
   // beams of the last pb_emit_beams: beams_const list, then beams_scattered list
@@ -242,7 +243,8 @@ int pb_lbvh_download(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes
   } while (0)
 
 // launchers implemented in the kernel translation units
-int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matrix16, TriPrep* d_out, hipStream_t s);
+int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matrix16, TriPrep* d_out,
+                            float4* d_screen_box, hipStream_t s);
 int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float scattering_c, SegFrame* d_frames,
                                float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s);
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);

@@ -85,7 +85,7 @@ PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
   const V4 start = v4(0, 0, 0, 1);
   V4 pos = v4(0, 0, 0, 0);
   float dist; int idx;
-  r.active = closest_intersection(p.tris, p.n_tri, start, dir, pos, dist, idx);
+  r.active = closest_intersection(p.tris, p.n_tri, start, dir, pos, dist, idx, p.tri_box);
   r.maxd = r.active ? length4(pos - start) : -1.0f;
   r.l = normalize3(xyz(dir));
   r.dn = xyz(normalize4(dir));

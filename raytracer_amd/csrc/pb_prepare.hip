@@ -8,7 +8,7 @@
 // ClosestIntersection, Intersections.h:468-476: v = matrix * triangle vertex,
 // e1 = v1 - v0, e2 = v2 - v0, and the cofactors of columns 1,2 of A = (-dir,e1,e2).
 __global__ void prepare_scene_kernel(const float* __restrict__ tri_xyz, int n_tri, const float* __restrict__ matrix,
-                                     TriPrep* __restrict__ out) {
+                                     TriPrep* __restrict__ out, float4* __restrict__ screen_box) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_tri) return;
   float m[16];
@@ -32,6 +32,16 @@ __global__ void prepare_scene_kernel(const float* __restrict__ tri_xyz, int n_tr
   p.n[0] = n.x; p.n[1] = n.y; p.n[2] = n.z;
   p.pad = 0.0f;
   out[i] = p;
+  // bounds of x/z and y/z seen from the camera at (0,0,0); unbounded if a vertex is beside or behind it
+  float4 sb = make_float4(-3.402823466e+38f, 3.402823466e+38f, -3.402823466e+38f, 3.402823466e+38f);
+  if (v0.z > 0.05f && v1.z > 0.05f && v2.z > 0.05f) {
+    const float u0 = v0.x / v0.z, u1 = v1.x / v1.z, u2 = v2.x / v2.z;
+    const float w0 = v0.y / v0.z, w1 = v1.y / v1.z, w2 = v2.y / v2.z;
+    const float m = 1e-3f;
+    sb = make_float4(fminf(u0, fminf(u1, u2)) - m, fmaxf(u0, fmaxf(u1, u2)) + m,
+                     fminf(w0, fminf(w1, w2)) - m, fmaxf(w0, fmaxf(w1, w2)) + m);
+  }
+  screen_box[i] = sb;
 }
 
 // findRotationMatrix, Intersections.h:499-513.
@@ -138,8 +148,10 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
   het[i] = h;
 }
 
-int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_matrix16, TriPrep* d_out, hipStream_t s) {
-  hipLaunchKernelGGL(prepare_scene_kernel, dim3((n_tri + 63) / 64), dim3(64), 0, s, d_tri_xyz, n_tri, d_matrix16, d_out);
+int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_matrix16, TriPrep* d_out,
+                            float4* d_screen_box, hipStream_t s) {
+  hipLaunchKernelGGL(prepare_scene_kernel, dim3((n_tri + 63) / 64), dim3(64), 0, s, d_tri_xyz, n_tri, d_matrix16, d_out,
+                     d_screen_box);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }
