@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, i
 
 // The steps between the two binning passes in one block (frames of up to QUEUE_FUSED_TILES tiles):
 // list offsets of the macro tiles, their rank by list length, items per queue slot and their prefix sum.  Small frames spend more time between launches than in these steps.
-constexpr int QUEUE_FUSED_TILES = 16384;           // 256 macro tiles, 16384 queue slots
+constexpr int QUEUE_FUSED_TILES = 256 * PB_MACRO * PB_MACRO;   // 256 macro tiles
 constexpr int QUEUE_THREADS = 1024;
 __global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const RenderParams p, int n_macro) {
   __shared__ uint32_t s_cnt[256], s_inv[256], s_part[QUEUE_THREADS / 64];
