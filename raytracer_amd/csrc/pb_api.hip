@@ -143,8 +143,13 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
   for (int attempt = 0; attempt < 4; ++attempt) {
     int rc = ensure_workspace(ctx, groups, 0);
     if (rc != PB_OK) return rc;
-    const int mtiles = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
-    const int slots = mtiles * PB_MACRO * PB_MACRO;     // queue slots: every macro tile has room for all its tiles
+    // With interleaved strips a macro tile takes fewer tile rows: eight would span strip_stride times the
+    // height on screen and hand every tile the segments of a whole column to refine.
+    p.macro_h = PB_MACRO / p.strip_stride;     // keeps a macro tile's footprint at 64 image rows
+    if (p.macro_h < 1) p.macro_h = 1;
+    if (const char* e = std::getenv("PB_TUNE_MACROH")) { int v = std::atoi(e); if (v >= 1 && v <= PB_MACRO) p.macro_h = v; }
+    const int mtiles = pb_macro_count(p);
+    const int slots = mtiles * PB_MACRO * p.macro_h;     // queue slots: every macro tile has room for all its tiles
     rc = ensure_bin_workspace(ctx, slots, want_bins, want_items, px);
     if (rc != PB_OK) return rc;
     p.rays = ctx->d_rays; p.group_last = ctx->d_group_last; p.ctrl = ctx->d_ctrl;
@@ -156,7 +161,7 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
     }
     p.bin_list = ctx->d_bin_list; p.items = ctx->d_items; p.accum = ctx->d_accum;
     p.bin_capacity = ctx->ws_bin_cap; p.item_capacity = ctx->ws_item_cap;
-    p.fused_queue = (tiles <= pb_fused_queue_tiles()) ? 1 : 0;
+    p.fused_queue = (mtiles <= pb_fused_queue_macros()) ? 1 : 0;
     PB_HIP(hipEventRecord(ctx->ev[0], s));
     if (!p.fused_queue) {
       PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
@@ -229,7 +234,9 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
     p.lbvh_n = ctx->lb_n;
   }
   p.precise = ctx->precise ? 1 : 0;
-  p.slice = ctx->tune_slice; p.eval_waves = ctx->tune_waves; p.ablate = ctx->tune_ablate;
+  // a rank's share of interleaved strips has few items: shorter ones keep the longest wave short
+  p.slice = ctx->tune_slice > 0 ? ctx->tune_slice : (strip_stride > 1 ? 96 : 192);
+  p.eval_waves = ctx->tune_waves; p.ablate = ctx->tune_ablate;
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
 

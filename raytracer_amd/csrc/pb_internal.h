@@ -121,6 +121,7 @@ struct RenderParams {
   uint32_t* macro_rank;     // [macro tiles] position in the evaluation queue, longest list first
   unsigned long long* accum;// [out_h*out_w][3] fixed-point radiance sums
   int bin_capacity, item_capacity;
+  int macro_h;              // tile rows per macro tile: PB_MACRO, or 1 when the rows are interleaved strips
   int fused_queue;          // 1: ray set-up clears the accumulators and one block builds the queue (small frames)
   int n_items_host;         // number of items of this frame as measured when the workspace was sized
   int slice;                // candidates of a macro list per evaluation item (<= PB_SLICE)
@@ -138,7 +139,7 @@ constexpr int PB_RAY_WORDS = 12;       // floats stored per camera ray
 constexpr int PB_CHUNK = 124;          // candidates per chunk
 constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 512 B
 constexpr int PB_EVAL_WAVES = 256 * 32;
-constexpr int PB_MACRO = 8;             // a macro tile is PB_MACRO x PB_MACRO tiles (64 x 64 pixels)
+constexpr int PB_MACRO = 8;             // a macro tile is PB_MACRO tiles wide and RenderParams::macro_h tiles tall
 constexpr int PB_SLICE = 512;           // candidates of a macro list handed to one evaluation item
 constexpr int PB_BIN_FAN = 8;            // lanes that share the macro rows of one segment in the binning passes
 constexpr int PB_BIN_SUBS = 1;          // sub-counters per tile in the binning passes (power of two)
@@ -222,7 +223,7 @@ struct pb_ctx {
   bool count_on = false;
   bool precise = false;
   int tune_ablate = 0;
-  int tune_slice = 192, tune_waves = 0;   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
+  int tune_slice = 0, tune_waves = 0;     // 0: defaults chosen per frame   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
   pb_stats stats;
 };
 
@@ -251,7 +252,10 @@ int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);
 int pb_launch_bin_count(const RenderParams& p, hipStream_t s);
-int pb_fused_queue_tiles(void);
+int pb_fused_queue_macros(void);
+PB_HDI int pb_macro_count(const RenderParams& p) {
+  return ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
+}
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s);
 
 #endif

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
       a[0] = 0ull; a[64] = 0ull; a[128] = 0ull;
     }
     if (group == 0) {
-      const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
+      const int n_macro = pb_macro_count(p);
       for (int i = lane; i < n_macro; i += 64) { p.sub_count[i] = 0u; p.sub_fill[i] = 0u; }
     }
   }
@@ -440,7 +440,7 @@ PB_DI TileRect macro_rect(const RenderParams& p, V3 a, V3 b, float pad, int mtx,
   }
   // sub-ray coordinate s = u * focal + half; pixel = s / ssaa; one pixel of margin
   const float inv = 1.0f / (float)p.ssaa;
-  const float sx = 1.0f / (float)(8 * PB_MACRO), sy = 1.0f / (float)(8 * PB_MACRO * p.strip_stride);
+  const float sx = 1.0f / (float)(8 * PB_MACRO), sy = 1.0f / (float)(8 * p.macro_h * p.strip_stride);
   const float fx0 = ((lo[0] * p.focal + half_w) * inv - 1.0f - (float)p.x0) * sx;
   const float fx1 = ((hi[0] * p.focal + half_w) * inv + 1.0f - (float)p.x0) * sx;
   const float fy0 = ((lo[1] * p.focal + half_h) * inv - 1.0f - (float)p.y0) * sy;
@@ -474,8 +474,8 @@ PB_DI void for_each_macro_tile(const RenderParams& p, const float4 A4, const flo
   for (int my = rc.y0 + k; my <= rc.y1; my += PB_BIN_FAN) {
     // rows of the macro tile (with interleaved strips its tile rows are strip_stride apart; the pyramid
     // then also spans the rows in between: conservative)
-    const int tk0 = my * PB_MACRO;
-    int tk1 = tk0 + PB_MACRO - 1;
+    const int tk0 = my * p.macro_h;
+    int tk1 = tk0 + p.macro_h - 1;
     if (tk1 > p.tiles_y - 1) tk1 = p.tiles_y - 1;
     const int py0 = p.y0 + 8 * tk0 * p.strip_stride, py1 = p.y0 + 8 * tk1 * p.strip_stride + 7;
     const float yt = (float)(py0 * p.ssaa) - half_h - 0.5f;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const RenderParams p, 
   extern __shared__ uint32_t bin_lds[];      // [n_macro] counts, [n_macro] bases
   uint32_t* lcount = bin_lds;
   uint32_t* lbase = bin_lds + n_macro;
-  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO, mty = (p.tiles_y + PB_MACRO - 1) / PB_MACRO;
+  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO, mty = (p.tiles_y + p.macro_h - 1) / p.macro_h;
   const long long g = (long long)blockIdx.x * BIN_THREADS + threadIdx.x;
   const int s = (int)(g / PB_BIN_FAN), k = (int)(g % PB_BIN_FAN);
   const bool live = s < p.n_seg;
@@ -572,12 +572,12 @@ __global__ __launch_bounds__(256) void macro_rank_kernel(const RenderParams p, i
   p.macro_rank[m] = rank;
 }
 
-// Queue slot of tile t: macro tiles in rank order, PB_MACRO^2 slots each.
+// Queue slot of tile t: macro tiles in rank order, PB_MACRO x macro_h slots each.
 PB_DI int tile_slot(const RenderParams& p, int t, int& m) {
   const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
   const int tx = t % p.tiles_x, tk = t / p.tiles_x;
-  m = (tk / PB_MACRO) * mtx + tx / PB_MACRO;
-  return (int)p.macro_rank[m] * (PB_MACRO * PB_MACRO) + (tk % PB_MACRO) * PB_MACRO + tx % PB_MACRO;
+  m = (tk / p.macro_h) * mtx + tx / PB_MACRO;
+  return (int)p.macro_rank[m] * (PB_MACRO * p.macro_h) + (tk % p.macro_h) * PB_MACRO + tx % PB_MACRO;
 }
 
 // Items of a tile: the list of its macro tile cut into slices of p.slice, for each sub-sample group.
@@ -617,9 +617,9 @@ __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, i
   }
 }
 
-// The steps between the two binning passes in one block (frames of up to QUEUE_FUSED_TILES tiles):
+// The steps between the two binning passes in one block (frames of up to QUEUE_FUSED_MACROS macro tiles):
 // list offsets of the macro tiles, their rank by list length, items per queue slot and their prefix sum.  Small frames spend more time between launches than in these steps.
-constexpr int QUEUE_FUSED_TILES = 256 * PB_MACRO * PB_MACRO;   // 256 macro tiles
+constexpr int QUEUE_FUSED_MACROS = 256;            // macro tiles the single-block queue build holds in LDS
 constexpr int QUEUE_THREADS = 1024;
 __global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const RenderParams p, int n_macro) {
   __shared__ uint32_t s_cnt[256], s_inv[256], s_part[QUEUE_THREADS / 64];
@@ -641,14 +641,15 @@ __global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const Render
     if (t == n_macro - 1) p.ctrl[2] = off + mine;
   }
   __syncthreads();
-  const int slots = n_macro * PB_MACRO * PB_MACRO;
+  const int per_macro = PB_MACRO * p.macro_h;
+  const int slots = n_macro * per_macro;
   const int per = (slots + QUEUE_THREADS - 1) / QUEUE_THREADS;
   const int slot0 = t * per;
   // tile, list length and number of active groups of a slot; tile < 0: no tile there
   auto slot_info = [&](int slot, uint32_t& cnt, uint32_t& m) -> int {
-    m = s_inv[slot / (PB_MACRO * PB_MACRO)];
-    const int local = slot % (PB_MACRO * PB_MACRO);
-    const int tx = (int)(m % mtx) * PB_MACRO + local % PB_MACRO, tk = (int)(m / mtx) * PB_MACRO + local / PB_MACRO;
+    m = s_inv[slot / per_macro];
+    const int local = slot % per_macro;
+    const int tx = (int)(m % mtx) * PB_MACRO + local % PB_MACRO, tk = (int)(m / mtx) * p.macro_h + local / PB_MACRO;
     cnt = s_cnt[m];
     return (tx < p.tiles_x && tk < p.tiles_y) ? tk * p.tiles_x + tx : -1;
   };
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
 
 }  // namespace
 
-int pb_fused_queue_tiles(void) { return QUEUE_FUSED_TILES; }
+int pb_fused_queue_macros(void) { return QUEUE_FUSED_MACROS; }
 
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
   (void)mode;
@@ -872,7 +873,7 @@ int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
 int pb_launch_bin_count(const RenderParams& p, hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
-  const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
+  const int n_macro = pb_macro_count(p);
   if (p.n_seg > 0) {
     const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
     if (n_macro <= BIN_LDS_MACROS)
@@ -894,7 +895,7 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
   if (p.n_seg > 0) {
-    const int n_macro = ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + PB_MACRO - 1) / PB_MACRO);
+    const int n_macro = pb_macro_count(p);
     const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
     if (n_macro <= BIN_LDS_MACROS)
       hipLaunchKernelGGL((bin_kernel<true, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);

@@ -199,3 +199,35 @@ def test_supersampling_matches_oracle(pb, ssaa):
         assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), (name, err.max())
         assert np.sqrt((err ** 2).mean()) <= 1e-4, name
     np.testing.assert_allclose(part, frames["bins"][16:40, 8:48], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_rank_strips_reassemble_to_the_single_gpu_frame(pb, world):
+    """The N-GPU path of bench.py in one process: every rank's strips (tiles.strips_of_rank) rendered by
+    draw_strips_device with the segment set uploaded from a device buffer, then put in image order by
+    tiles.assemble - bit-identical to the frame one GPU renders (binned mode, fixed-point sums)."""
+    import torch
+    from raytracer_amd import tiles
+    kw = dict(photon_number=1500, bounces=2, screen_width=256, screen_height=256)
+    H = W = 256
+    with pb.Context(pb.control_defaults(**kw)) as src:
+        src.set_scene()
+        src.cast_photon_beams()
+        segs = src.download_segments()
+        lo, hi = src.root_box()
+        full = src.draw(cull="bins")
+    stream = torch.cuda.current_stream().cuda_stream
+    d_segs = torch.from_numpy(segs.view(np.uint8).reshape(-1).copy()).cuda()
+    first, stride, n_my = tiles.strips_of_rank(H, 0, world)
+    gathered = torch.zeros((world, n_my * 8, W, 3), dtype=torch.float32, device="cuda")
+    for rank in range(world):
+        first, stride, n_my = tiles.strips_of_rank(H, rank, world)
+        with pb.Context(pb.control_defaults(**kw)) as ctx:
+            ctx.set_scene()
+            ctx.upload_segments_device(d_segs.data_ptr(), len(segs), lo, hi, stream=stream)
+            torch.cuda.synchronize()
+            ctx.draw_strips_device(gathered[rank].data_ptr(), first, stride, n_my, cull="bins", stream=stream)
+            torch.cuda.synchronize()
+    frame = tiles.assemble(gathered, torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
+    assert np.array_equal(frame.cpu().numpy(), full)
+    assert full.max() > 1.0
