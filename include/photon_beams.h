@@ -121,8 +121,10 @@ typedef struct pb_stats {
 
 typedef struct pb_ctx pb_ctx;
 
-enum { PB_MODE_721 = 721,      /* BeamRadianceStandard + Integral_721            */
-       PB_MODE_73HET = 73 };   /* BVHBeamRadianceHet + Integral_73Het            */
+enum { PB_MODE_721 = 721,      /* BeamRadianceStandard + Integral_721 (BeamRadiance.h:415-469, :86-110)             */
+       PB_MODE_73HET = 73,     /* BVHBeamRadianceHet + Integral_73Het (:356-414, :211-288); needs pb_set_grid       */
+       PB_MODE_73 = 730 };     /* BeamRadiance with ONE_DIMENSIONAL in a homogeneous medium: Integral_73 (:510-524,
+                                  :112-209 with HETEROGENEOUS false)                                                  */
 
 /* Control.h:4-50 defaults. */
 void pb_control_defaults(pb_control* c);

@@ -430,8 +430,9 @@ static double Integral_721(const PhotonSeg& s, const CylIntersection& i, float e
 }
 
 // BeamRadiance.h:211-288
+// het == false is Integral_73 (:112-209) with HETEROGENEOUS off: sigma_t along both paths, sigma_s as is.
 static double Integral_73Het(const Grid& GRID, const PhotonSeg& s, const CylIntersection& i, float extinction_c,
-                             float scattering_c, vec4 dir) {
+                             float scattering_c, vec4 dir, bool het = true) {
   double transmitted = 0;
   dvec3 a = D3(xyz(s.start)), c = D3(i.exit_point);
   dvec3 b = D3(xyz(s.end)), d = D3(i.entry_point);
@@ -453,13 +454,18 @@ static double Integral_73Het(const Grid& GRID, const PhotonSeg& s, const CylInte
     if (bound1 && bound2) {
       double t_bc = dlength(point_beam - os);
       double t_cb = view_distance;
-      float proportion = (float)((t_bc - dlength(a - os)) / (dlength(b - os) - dlength(a - os)));
-      float additional = s.s_ext + ((s.e_ext - s.s_ext) * proportion);
-      float beam_extinction = s.c_ext + ((additional - s.c_ext) / (s.seg_id + 1));
-      std::vector<vec2> dist_ext;
-      float view_extinction = Extinction3D(GRID, V4(0, 0, 0, 1), V4(0, 0, 0, 1) + (dir * (float)t_cb), dist_ext);
-      transmitted = Transmittance(t_bc, beam_extinction) * Transmittance(t_cb, view_extinction);
-      float scattering = (beam_extinction / extinction_c) * scattering_c;
+      float scattering = scattering_c;
+      if (het) {
+        float proportion = (float)((t_bc - dlength(a - os)) / (dlength(b - os) - dlength(a - os)));
+        float additional = s.s_ext + ((s.e_ext - s.s_ext) * proportion);
+        float beam_extinction = s.c_ext + ((additional - s.c_ext) / (s.seg_id + 1));
+        std::vector<vec2> dist_ext;
+        float view_extinction = Extinction3D(GRID, V4(0, 0, 0, 1), V4(0, 0, 0, 1) + (dir * (float)t_cb), dist_ext);
+        transmitted = Transmittance(t_bc, beam_extinction) * Transmittance(t_cb, view_extinction);
+        scattering = (beam_extinction / extinction_c) * scattering_c;
+      } else {
+        transmitted = Transmittance(t_bc, extinction_c) * Transmittance(t_cb, extinction_c);
+      }
       if (transmitted < 1e-6) return 0;
       double cos_theta = ddot(ab, cd);
       double sin_theta = std::sqrt(1 - std::pow(cos_theta, 2));
@@ -944,7 +950,8 @@ static inline void leaf_segment(const PhotonSeg& seg, const dvec3& energy, const
         double rad = med.scattering_c / (PI_REF * ((double)seg.radius * (double)seg.radius));
         current = current + (energy * phase_f) * rad * _int;
       } else {
-        double _int = Integral_73Het(*med.grid, seg, isect, med.extinction_c, med.scattering_c, r.dir);
+        double _int = Integral_73Het(*med.grid, seg, isect, med.extinction_c, med.scattering_c, r.dir,
+                                     mode == PB_MODE_73HET);
         current = current + (energy * phase_f) * _int;
       }
     }
@@ -1362,7 +1369,8 @@ int orc_lbvh(const pb_segment* segs, int n, uint64_t* keys_out, uint32_t* perm_o
   std::vector<int> order; order.reserve(n - 1);
   { std::vector<int> st; st.push_back(0);
     while (!st.empty()) { int v = st.back(); st.pop_back(); order.push_back(v);
-      if (left[v] >= 0) st.push_back(left[v]); if (right[v] >= 0) st.push_back(right[v]); } }
+      if (left[v] >= 0) st.push_back(left[v]);
+      if (right[v] >= 0) st.push_back(right[v]); } }
   for (int q = (int)order.size() - 1; q >= 0; --q) {
     const int v = order[q];
     const float* a = left[v] >= 0 ? &node_box[6 * (size_t)left[v]] : &leaf_box[6 * (size_t)(~left[v])];

@@ -59,7 +59,8 @@ int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
 namespace {
 
 int default_mode(const pb_ctx* ctx) {
-  return (ctx->ctl.heterogeneous && ctx->ctl.one_dimensional) ? PB_MODE_73HET : PB_MODE_721;
+  if (ctx->ctl.heterogeneous && ctx->ctl.one_dimensional) return PB_MODE_73HET;
+  return ctx->ctl.one_dimensional ? PB_MODE_73 : PB_MODE_721;
 }
 
 }  // namespace
@@ -206,7 +207,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
                   float* d_out, hipStream_t s) {
   if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
   if (!ctx->have_segments) { pb_set_error("pb_render: no segment set (pb_upload_segments / pb_emit_beams)"); return PB_ERR_STATE; }
-  if (mode != PB_MODE_721 && mode != PB_MODE_73HET) { pb_set_error("pb_render: mode must be PB_MODE_721 or PB_MODE_73HET"); return PB_ERR_ARG; }
+  if (mode != PB_MODE_721 && mode != PB_MODE_73HET && mode != PB_MODE_73) { pb_set_error("pb_render: mode must be PB_MODE_721, PB_MODE_73 or PB_MODE_73HET"); return PB_ERR_ARG; }
   if (use_lbvh < 0 || use_lbvh > 2) { pb_set_error("pb_render: cull mode must be 0 (scan), 1 (LBVH) or 2 (screen bins)"); return PB_ERR_ARG; }
   if (use_lbvh == 1 && (ctx->lb_n < 0 || ctx->lb_version != ctx->segs_version)) {
     pb_set_error("pb_render: pb_build_lbvh has not been called for this segment set"); return PB_ERR_STATE;
@@ -224,7 +225,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.focal = (float)(ctx->ctl.screen_width * ctx->ctl.ssaa);      // rasteriser.h:17
   p.extinction_c = ctx->ctl.absorption_c + ctx->ctl.scattering_c; // Control.h:48
   p.scattering_c = ctx->ctl.scattering_c;
-  p.het = ctx->d_het; p.grid_z = ctx->d_grid; p.grid_side = ctx->grid_side;
+  p.het = ctx->d_het; p.grid_z = (mode == PB_MODE_73HET) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side;
   if (mode == PB_MODE_73HET && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_73HET needs pb_set_grid"); return PB_ERR_STATE; }
   p.x0 = x0; p.y0 = y0; p.out_w = out_w; p.out_h = out_h; p.strip_stride = strip_stride;
   p.tiles_x = (out_w + 7) / 8; p.tiles_y = (out_h + 7) / 8;

@@ -187,7 +187,8 @@ PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, doubl
   return 2;
 }
 
-// Integral_73Het (BeamRadiance.h:211-288): closest approach of the beam axis and the view ray in
+// Integral_73Het (BeamRadiance.h:211-288) and, with no grid, Integral_73 (:112-209) for a homogeneous
+// medium: closest approach of the beam axis and the view ray in
 // double, the beam's extinction interpolated within the segment, the view ray's extinction by a
 // walk through the grid from the camera to the point of closest approach.
 struct D3v { double x, y, z; };
@@ -223,15 +224,22 @@ PB_DI double integral_73het(const GridView& grid, V3 seg_start, V3 seg_end, cons
   if (!(bound1 && bound2)) return 0.0;
   const double t_bc = beam_distance;
   const double t_cb = view_distance;
-  const float proportion = (float)((t_bc - a_os) / (b_os - a_os));
-  const float additional = hf.s_ext + ((hf.e_ext - hf.s_ext) * proportion);
-  const float beam_extinction = hf.c_ext + ((additional - hf.c_ext) / (hf.seg_id + 1));
-  // vec4(0,0,0,1) + dir * (float) t_cb, dir the vec4 DrawHet normalised once (skeleton.cpp:383-387)
-  const float reach = (float)t_cb;
-  const V3 view_end = v3(0.0f + (r.d1.x * reach), 0.0f + (r.d1.y * reach), 0.0f + (r.d1.z * reach));
-  const float view_extinction = extinction3d_mean(grid, v3(0, 0, 0), view_end);
-  const double transmitted = exp(-(double)beam_extinction * t_bc) * exp(-(double)view_extinction * t_cb);
-  const float scattering = (beam_extinction / extinction_c) * scattering_c;
+  double transmitted;
+  float scattering = scattering_c;
+  if (grid.z) {
+    const float proportion = (float)((t_bc - a_os) / (b_os - a_os));
+    const float additional = hf.s_ext + ((hf.e_ext - hf.s_ext) * proportion);
+    const float beam_extinction = hf.c_ext + ((additional - hf.c_ext) / (hf.seg_id + 1));
+    // vec4(0,0,0,1) + dir * (float) t_cb, dir the vec4 DrawHet normalised once (skeleton.cpp:383-387)
+    const float reach = (float)t_cb;
+    const V3 view_end = v3(0.0f + (r.d1.x * reach), 0.0f + (r.d1.y * reach), 0.0f + (r.d1.z * reach));
+    const float view_extinction = extinction3d_mean(grid, v3(0, 0, 0), view_end);
+    transmitted = exp(-(double)beam_extinction * t_bc) * exp(-(double)view_extinction * t_cb);
+    scattering = (beam_extinction / extinction_c) * scattering_c;
+  } else {
+    // Integral_73 in a homogeneous medium (BeamRadiance.h:189-192): sigma_t along both paths
+    transmitted = exp(-(double)extinction_c * t_bc) * exp(-(double)extinction_c * t_cb);
+  }
   if (transmitted < 1e-6) return 0.0;
   const double cos_theta = ddot(ab, cd);
   const double sin_theta = __builtin_sqrt(1 - cos_theta * cos_theta);

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void probe_pair_kernel(const SegFrame* __restri
   double val = 0.0;
   int st;
   unsigned long long wrong = 0;
-  if (mode == PB_MODE_73HET) {
+  if (mode != PB_MODE_721) {
     const float4 A = capA[i], B = capB[i];
     st = eval_pair_73het(f, het[i], v3(A.x, A.y, A.z), v3(B.x, B.y, B.z), grid, r, extinction_c, scattering_c, val);
   } else if (fast) st = eval_pair_721_fast<false>(f, r, extinction_c, val, wrong);
@@ -160,7 +160,7 @@ extern "C" int pb_probe_hit_bounding_box(pb_ctx* ctx, const float* lo_xyz, const
 extern "C" int pb_probe_pairs(pb_ctx* ctx, const pb_segment* segs, const float* dir_xyzw, int n, int mode, int fast,
                               float* cyl_out12, double* integral, int32_t* status) {
   if (!ctx || !segs || !dir_xyzw || !cyl_out12 || !integral || !status || n < 0) { pb_set_error("pb_probe_pairs: bad argument"); return PB_ERR_ARG; }
-  if (mode != PB_MODE_721 && mode != PB_MODE_73HET) { pb_set_error("pb_probe_pairs: mode must be PB_MODE_721 or PB_MODE_73HET"); return PB_ERR_ARG; }
+  if (mode != PB_MODE_721 && mode != PB_MODE_73HET && mode != PB_MODE_73) { pb_set_error("pb_probe_pairs: mode must be PB_MODE_721, PB_MODE_73 or PB_MODE_73HET"); return PB_ERR_ARG; }
   if (mode == PB_MODE_73HET && !ctx->d_grid) { pb_set_error("pb_probe_pairs: PB_MODE_73HET needs pb_set_grid"); return PB_ERR_STATE; }
   if (n == 0) return PB_OK;
   PB_HIP(hipSetDevice(ctx->device));
@@ -179,7 +179,7 @@ extern "C" int pb_probe_pairs(pb_ctx* ctx, const pb_segment* segs, const float* 
   int rc = pb_launch_prepare_segments(d_segs, n, mode, ctx->ctl.scattering_c, d_frames, d_capA, d_capB, d_het, s);
   if (rc != PB_OK) return rc;
   GridView g;
-  g.z = ctx->d_grid; g.side = ctx->grid_side;
+  g.z = (mode == PB_MODE_73HET) ? ctx->d_grid : nullptr; g.side = ctx->grid_side;
   hipLaunchKernelGGL(probe_pair_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_frames, d_het, d_capA, d_capB, g, d_dir, n, mode,
                      fast, ctx->ctl.absorption_c + ctx->ctl.scattering_c, ctx->ctl.scattering_c, d_cyl, d_int, d_status);
   PB_HIP(hipGetLastError());

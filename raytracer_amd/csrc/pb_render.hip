@@ -846,7 +846,7 @@ int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream
   int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;   // one wave per chunk
   if (waves > p.chunk_capacity) waves = p.chunk_capacity;
   if (waves < 1) waves = 1;
-  if (mode == PB_MODE_73HET) {
+  if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
     if (count) hipLaunchKernelGGL((eval_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
     else hipLaunchKernelGGL((eval_kernel<false, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
   }
@@ -906,7 +906,7 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;
   if (waves > p.item_capacity) waves = p.item_capacity;
   if (waves < 1) waves = 1;
-  if (mode == PB_MODE_73HET) {
+  if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
     if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
     else hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
   }

@@ -15,6 +15,7 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref.so")
 
 MODE_721 = 721
 MODE_73HET = 73
+MODE_73 = 730
 
 
 class Control(C.Structure):

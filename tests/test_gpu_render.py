@@ -231,3 +231,25 @@ def test_rank_strips_reassemble_to_the_single_gpu_frame(pb, world):
     frame = tiles.assemble(gathered, torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
     assert np.array_equal(frame.cpu().numpy(), full)
     assert full.max() > 1.0
+
+
+def test_one_dimensional_homogeneous_estimator(pb):
+    """ONE_DIMENSIONAL in a homogeneous medium: BeamRadiance's Integral_73 branch (BeamRadiance.h:510-524).
+    Double arithmetic in the reference's order: the frame agrees to the float32 rounding of the output."""
+    kw = dict(photon_number=800, bounces=1, screen_width=128, screen_height=128, one_dimensional=1)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        ctx.build_tree()
+        frames = {c: ctx.draw(mode=pb.MODE_73, cull=c).astype(np.float64) for c in ("scan", "lbvh", "bins")}
+        std = ctx.draw(mode=pb.MODE_721, cull="bins")
+    tri, _ = orc.load_test_model()
+    ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
+                                   segs, lo, hi, 0, 0, 128, 128, mode=orc.MODE_73)
+    assert ref.max() > 0.05 and cnt["valid_hits"] > 50000
+    for name, img in frames.items():
+        err = np.abs(img - ref)
+        assert (err <= 1e-6 * np.maximum(1.0, np.abs(ref))).all(), (name, err.max())
+    assert not np.allclose(std, frames["bins"], rtol=0.05)     # a different estimator, not the 2D one
