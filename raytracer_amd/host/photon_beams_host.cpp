@@ -226,7 +226,8 @@ void PutPixelSDL(screen* s, int x, int y, vec3 colour) {
 void SDL_Renderframe(screen*) {}
 
 // 32-bit BMP with BI_BITFIELDS masks (A 0xff000000, R 0x00ff0000, G 0x0000ff00, B 0x000000ff), bottom-up,
-// as SDL_SaveBMP writes an ARGB8888 surface.
+// as SDL_SaveBMP writes an ARGB8888 surface (pixels-per-metre fields zero): the header equals the reference's
+// screenshot.bmp byte for byte.
 void SDL_SaveImage(screen* s, const char* filename) {
   const uint32_t w = (uint32_t)s->width, h = (uint32_t)s->height, data = w * h * 4, off = 14 + 108;
   unsigned char hdr[14 + 108];
@@ -235,7 +236,6 @@ void SDL_SaveImage(screen* s, const char* filename) {
   auto put16 = [&](int at, uint32_t v) { hdr[at] = (unsigned char)v; hdr[at + 1] = (unsigned char)(v >> 8); };
   hdr[0] = 'B'; hdr[1] = 'M'; put32(2, off + data); put32(10, off);
   put32(14, 108); put32(18, w); put32(22, h); put16(26, 1); put16(28, 32); put32(30, 3); put32(34, data);
-  put32(38, 2835); put32(42, 2835);
   put32(54, 0x00ff0000u); put32(58, 0x0000ff00u); put32(62, 0x000000ffu); put32(66, 0xff000000u);
   put32(70, 0x57696e20u);   // "Win " colour space
   FILE* f = std::fopen(filename, "wb");

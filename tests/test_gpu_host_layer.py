@@ -45,6 +45,20 @@ def test_standard_run_through_reference_named_functions(tmp_path):
     assert (img & 0xFF).max() > 100
 
 
+def test_bmp_header_equals_the_reference_screenshot(tmp_path):
+    """SDL_SaveImage (SDLauxiliary.h:24-53): 122-byte V4 header, BI_BITFIELDS ARGB masks, bottom-up - the
+    first 122 bytes of the reference's own 512x512 screenshot.bmp (tests/golden)."""
+    out = str(tmp_path / "shot512.bmp")
+    r = subprocess.run([EXE, "200", "0", "512", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    raw = open(out, "rb").read()
+    want = open(os.path.join(ROOT, "tests", "golden", "reference_screenshot_bmp_header.bin"), "rb").read()
+    assert len(want) == 122 and len(raw) == 122 + 512 * 512 * 4
+    assert raw[:122] == want
+    px = np.frombuffer(raw, dtype="<u4", offset=122)
+    assert (px >> 24 == 128).all()          # PutPixelSDL's alpha (SDLauxiliary.h:160)
+
+
 def test_heterogeneous_run_through_reference_named_functions(tmp_path):
     """HeterogeneousRun: CreateSurface, GRID moved by the caller, CastPhotonBeams, DrawHet."""
     import raytracer_amd as pb
