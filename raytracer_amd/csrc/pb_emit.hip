@@ -9,6 +9,7 @@
 // obtained from prefix sums of per-photon / per-beam counts, i.e. in the order
 // the reference's sequential push_back would give: every kernel runs twice,
 // first counting, then writing.
+#include <cstddef>
 #include <cstring>
 
 #include "pb_internal.h"
@@ -434,16 +435,21 @@ __global__ __launch_bounds__(256) void bound_kernel(const BoundParams p) {
   if (!WRITE) p.seg_count[g] = count;
 }
 
-// Root box of CastPhotonBeams (CastPhotons.h:507-512, :384-387): bounds of all beam end points.
-__global__ __launch_bounds__(1024) void root_box_kernel(const pb_beam* __restrict__ beams, int n, float* __restrict__ out6) {
+// Root box of CastPhotonBeams (CastPhotons.h:507-512, :384-387): bounds of all beam end points.  Blocks write
+// one partial box each (grid-stride); a second launch of one block over those partials gives the result.
+constexpr int ROOT_BOX_BLOCKS = 256;
+__global__ __launch_bounds__(1024) void root_box_kernel(const float* __restrict__ pts6, int stride_floats, int n,
+                                                        float* __restrict__ out6) {
   __shared__ float red[6][1024 / 64];
   float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
   float hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const pb_beam b = beams[i];
+  // record i holds two points: floats 0..2 and 4..6 of a beam (start, end), or lo / hi of a partial box
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* r = pts6 + (size_t)i * stride_floats;
+    const int second = (stride_floats == 6) ? 3 : 4;
     for (int k = 0; k < 3; ++k) {
-      lo[k] = fminf(lo[k], fminf(b.start[k], b.end[k]));
-      hi[k] = fmaxf(hi[k], fmaxf(b.start[k], b.end[k]));
+      lo[k] = fminf(lo[k], fminf(r[k], r[second + k]));
+      hi[k] = fmaxf(hi[k], fmaxf(r[k], r[second + k]));
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(1024) void root_box_kernel(const pb_beam* __restric
     const int k = threadIdx.x;
     float v = red[k][0];
     for (int w = 1; w < 1024 / 64; ++w) v = (k < 3) ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
-    out6[k] = v;
+    out6[(size_t)blockIdx.x * 6 + k] = v;
   }
 }
 
@@ -478,13 +484,14 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
   const size_t n = (size_t)n_photons;
   const size_t scan_words = pb_scan_tmp_words(n_photons > 0 ? n_photons : 1);
   TmpBuffers tmp;
-  const size_t head = 4 * n + 16;
+  const size_t head = 4 * n + 16 + 6 * ROOT_BOX_BLOCKS;
   PB_HIP(hipMalloc(&tmp.a, sizeof(uint32_t) * (head + scan_words)));
   PB_HIP(hipMemsetAsync(tmp.a, 0, sizeof(uint32_t) * (head + scan_words), s));
   uint32_t* cnt_const = tmp.a; uint32_t* cnt_scatt = tmp.a + n;
   uint32_t* off_const = tmp.a + 2 * n; uint32_t* off_scatt = tmp.a + 3 * n;
   uint32_t* totals = tmp.a + 4 * n;            // [0] n_const [1] n_scatt [2] n_seg [3] dropped
   float* d_root = (float*)(tmp.a + 4 * n + 8); // 6 floats
+  float* d_root_partial = (float*)(tmp.a + 4 * n + 16);   // 6 floats per block of the first root-box launch
   uint32_t* scan_tmp = tmp.a + head;
 
   EmitParams ep;
@@ -535,7 +542,15 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
   PB_HIP(hipGetLastError());
   rc = pb_exclusive_scan_u32(seg_count, seg_offset, nb, totals + 2, scan_tmp2, s);
   if (rc != PB_OK) return rc;
-  if (nb > 0) hipLaunchKernelGGL(root_box_kernel, dim3(1), dim3(1024), 0, s, ctx->d_beams, nb, d_root);
+  if (nb > 0) {
+    static_assert(sizeof(pb_beam) % sizeof(float) == 0 && offsetof(pb_beam, start) == 0 && offsetof(pb_beam, end) == 16,
+                  "root_box_kernel reads start and end as floats 0..2 and 4..6 of a beam record");
+    int rb = (nb + 1023) / 1024;
+    if (rb > ROOT_BOX_BLOCKS) rb = ROOT_BOX_BLOCKS;
+    hipLaunchKernelGGL(root_box_kernel, dim3(rb), dim3(1024), 0, s, (const float*)ctx->d_beams,
+                       (int)(sizeof(pb_beam) / sizeof(float)), nb, d_root_partial);
+    hipLaunchKernelGGL(root_box_kernel, dim3(1), dim3(1024), 0, s, d_root_partial, 6, rb, d_root);
+  }
   PB_HIP(hipGetLastError());
   float h_root[6] = {0, 0, 0, 0, 0, 0};
   PB_HIP(hipMemcpyAsync(h_tot, totals, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
