@@ -222,6 +222,11 @@ def main():
             "frame_ok": frame_ok,
             "per_ray": {k: cnt[k] / rays for k in ("candidates", "cyl_hits", "valid_hits", "gate_passes")},
             "phases_ms": {k: cnt[k] for k in ("ms_emit", "ms_prepare", "ms_build")},
+            # one-time passes against HBM: algorithmic bytes (radix sort 6 passes x read+write x 12 B per segment,
+            # boxes and nodes 128 B per segment; beams 80 B and segments 112 B written twice over) / device time
+            "phases_gb_per_s": {
+                "lbvh_build": (6 * 2 * 12 + 128) * n_segs / (cnt["ms_build"] * 1e-3) / 1e9 if cnt["ms_build"] > 0 else None,
+                "photon_pass": (2 * 80 * n_beams + 2 * 112 * n_segs) / (cnt["ms_emit"] * 1e-3) / 1e9 if cnt["ms_emit"] > 0 else None},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, wk, segs, root[:3], root[3:], grid)
