@@ -144,23 +144,24 @@ def main():
 
     # ---- strips of this rank ----
     first_strip, strip_stride, n_my = tiles.strips_of_rank(H, rank, world)
-    mine = torch.zeros((n_my * 8, W, 3), dtype=torch.float32, device=dev)
-    gathered = torch.zeros((world, n_my * 8, W, 3), dtype=torch.float32, device=dev) if world > 1 else None
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    pipe = tiles.StripPipeline(world, n_my * 8, W, dev, frame=frame)   # the RCCL all-gather of frame k overlaps frame k + 1
     stream = torch.cuda.current_stream().cuda_stream
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(i=None):
+        slot = pipe.begin(frame)
         if i is not None:
             ev0[i].record()
-        ctx.draw_strips_device(mine.data_ptr(), first_strip, strip_stride, n_my, mode=mode, cull=cull, stream=stream)
+        ctx.draw_strips_device(pipe.mine[slot].data_ptr(), first_strip, strip_stride, n_my, mode=mode, cull=cull, stream=stream)
         if i is not None:
             ev1[i].record()
-        tiles.gather_frame(mine, gathered, frame, world)     # RCCL all-gather of the row tiles + reorder
+        pipe.submit(slot)
 
     for _ in range(args.warmup):
         step()
+    pipe.drain(frame)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -168,6 +169,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    pipe.drain(frame)              # every frame gathered and assembled inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

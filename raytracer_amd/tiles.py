@@ -47,6 +47,60 @@ def gather_frame(mine, gathered, frame, world):
     return assemble(gathered, frame)
 
 
+class StripPipeline:
+    """Double-buffered all-gather of the ranks' strips: the gather of frame k runs on the collective's
+    own stream while frame k + 1 is rendered, so the exchange is hidden behind compute.  Every frame is still
+    rendered, gathered and put in image order; only the order of the waits changes.
+
+        pipe = StripPipeline(world, rows_per_rank, width, device)
+        for k in range(frames):
+            slot = pipe.begin(frame)          # finishes the frame that used this slot two steps ago
+            render into pipe.mine[slot]
+            pipe.submit(slot)
+        pipe.drain(frame)
+    """
+
+    def __init__(self, world, rows, width, device, channels=3, depth=2, frame=None):
+        self.world = world
+        self.depth = depth
+        # one rank owns every strip: it renders straight into the frame, nothing to exchange or copy
+        self.direct = world == 1 and frame is not None and tuple(frame.shape) == (rows, width, channels)
+        self.mine = [frame if self.direct else torch.zeros((rows, width, channels), dtype=torch.float32, device=device)
+                     for _ in range(depth)]
+        self.gathered = [torch.zeros((world, rows, width, channels), dtype=torch.float32, device=device)
+                         if world > 1 else None for _ in range(depth)]
+        self.work = [None] * depth
+        self.filled = [False] * depth
+        self.k = 0
+
+    def _finish(self, slot, frame):
+        if not self.filled[slot]:
+            return
+        if self.world == 1:
+            if not self.direct:
+                frame.copy_(self.mine[slot])
+        else:
+            self.work[slot].wait()            # the current stream waits for that gather; the host does not
+            assemble(self.gathered[slot], frame)
+        self.filled[slot] = False
+
+    def begin(self, frame):
+        slot = self.k % self.depth
+        self._finish(slot, frame)
+        return slot
+
+    def submit(self, slot):
+        if self.world > 1:
+            g = self.gathered[slot]
+            self.work[slot] = dist.all_gather_into_tensor(g.view(-1, *g.shape[2:]), self.mine[slot], async_op=True)
+        self.filled[slot] = True
+        self.k += 1
+
+    def drain(self, frame):
+        for d in range(self.depth):
+            self._finish((self.k + d) % self.depth, frame)
+
+
 def broadcast_segments(segs, root_box, device, src=0, itemsize=112):
     """Broadcast the segment records (numpy structured array on `src`, None elsewhere) and the 6 floats of
     the root box.  Returns (byte tensor on `device` holding the records, n_segments, root_box as numpy)."""
