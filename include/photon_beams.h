@@ -188,6 +188,13 @@ int pb_get_root_box(pb_ctx* ctx, float root_lo[3], float root_hi[3]);
  * (seed, photon, draw), beams pushed in (photon, order) order.  The result
  * replaces the context's segment set (own-box cull rule) and root box. */
 int pb_emit_beams(pb_ctx* ctx, int n_photons, uint64_t seed, int* n_beams_out, int* n_segments_out);
+/* RecastPhotonBeams (CastPhotons.h:290-310) + BoundPhotonBeams as ProduceStopMotion uses them
+ * (skeleton.cpp:312-324): every beam of the first list is cast again from its start along its direction
+ * through the current medium (pb_set_grid), the scattered list is rebuilt from what that produces, the
+ * first list is kept, and both are cut into segments again.  Random numbers: (seed, beam index, draw).
+ * The reference's loop runs over the vector it appends to and does not terminate; exactly the beams
+ * present on entry are re-cast here.  The root box is the bounds of the kept and the new beams. */
+int pb_recast_beams(pb_ctx* ctx, uint64_t seed, int* n_scattered_out, int* n_segments_out);
 int pb_download_beams(pb_ctx* ctx, pb_beam* out, int capacity, int* n_out);  /* const list, then scattered list */
 int pb_beam_counts(pb_ctx* ctx, int* n_const, int* n_scattered);
 

@@ -748,6 +748,28 @@ struct Oracle {
     return root;
   }
 
+  // CastPhotons.h:290-310.  The reference loops `i < beams_const.size()` over the very vector CastBeam
+  // appends to, so it re-casts its own output and does not terminate; here only the beams present on
+  // entry are re-cast.  As there, the re-cast copies are discarded and the scattered list is rebuilt.
+  AABB RecastPhotonBeams() {
+    vec4 min_point = V4(M_BIG, M_BIG, -M_BIG, 1), max_point = V4(-M_BIG, -M_BIG, M_BIG, 1);
+    std::vector<PhotonBeam> copy = beams_const;
+    const size_t n0 = copy.size();
+    beams_scatt.clear();
+    for (size_t i = 0; i < n0; ++i) {
+      PhotonBeam beam = copy[i];
+      cur_photon = (uint32_t)i; cur_order = 0;
+      rng.photon = (uint32_t)i; rng.draw = 0;
+      vec4 direction = V4(normalize(xyz(beam.end) - xyz(beam.start)), 1.0f);
+      vec3 energy = V3((float)beam.energy.x, (float)beam.energy.y, (float)beam.energy.z);
+      CastBeam(0, energy, beam.start, direction, min_point, max_point, copy, beams_scatt, beam.radius, beam);
+    }
+    AABB root;
+    root.min = min_point; root.max = max_point;
+    root.mid = (min_point + max_point) / 2.0f;
+    return root;
+  }
+
   // CastPhotons.h:144-288
   void BoundPhotonBeams(std::vector<PhotonBeam>& beams) {
     const pb_control& C = ctl.c;
@@ -1169,6 +1191,15 @@ int orc_cast_photon_beams(orc_ctx* c, int number, int rng_kind) {
   o.beams_const.clear(); o.beams_scatt.clear();
   o.root_aabb = o.CastPhotonBeams(number);
   return (int)(o.beams_const.size() + o.beams_scatt.size());
+}
+// RecastPhotonBeams (terminating form, see above) with the random stream re-keyed by `seed`.
+int orc_recast_photon_beams(orc_ctx* c, int rng_kind, uint64_t seed) {
+  Oracle& o = c->o;
+  o.rng.kind = rng_kind;
+  o.rng.seed = seed;
+  if (rng_kind == 0) o.rng.generator.seed(seed);
+  o.root_aabb = o.RecastPhotonBeams();
+  return (int)o.beams_scatt.size();
 }
 int orc_beam_counts(orc_ctx* c, int* n_const, int* n_scatt) {
   *n_const = (int)c->o.beams_const.size(); *n_scatt = (int)c->o.beams_scatt.size();

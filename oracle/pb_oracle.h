@@ -54,6 +54,7 @@ void orc_destroy(orc_ctx*);
 /* CastPhotonBeams with std::mt19937(seed) (rng_kind 0) or the counter-based
  * generator the GPU emission uses (rng_kind 1). Returns beams_const.size()+beams_scatt.size(). */
 int  orc_cast_photon_beams(orc_ctx*, int number, int rng_kind);
+int  orc_recast_photon_beams(orc_ctx*, int rng_kind, uint64_t seed);   /* rebuilds the scattered list; returns its size */
 int  orc_beam_counts(orc_ctx*, int* n_const, int* n_scatt);
 int  orc_get_beams(orc_ctx*, pb_beam* out, int capacity);   /* const list then scattered list */
 int  orc_bound_photon_beams(orc_ctx*);                       /* both lists; returns items.size() */

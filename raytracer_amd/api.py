@@ -315,6 +315,13 @@ class Context:
         _check(self.L.pb_emit_beams(self.h, C.c_int(n), C.c_uint64(seed), C.byref(nb), C.byref(ns)), "pb_emit_beams")
         return nb.value, ns.value
 
+    def recast_photon_beams(self, seed=None):
+        """RecastPhotonBeams + BoundPhotonBeams: (scattered beams, segments) after re-casting the first list."""
+        a = C.c_int(0); b = C.c_int(0)
+        seed = self.control.seed if seed is None else seed
+        _check(self.L.pb_recast_beams(self.h, C.c_uint64(seed), C.byref(a), C.byref(b)), "pb_recast_beams")
+        return a.value, b.value
+
     def beam_counts(self):
         a = C.c_int(0); b = C.c_int(0)
         _check(self.L.pb_beam_counts(self.h, C.byref(a), C.byref(b)), "pb_beam_counts")

@@ -462,9 +462,22 @@ int pb_emit_beams(pb_ctx* ctx, int n_photons, uint64_t seed, int* n_beams_out, i
   if (!ctx->d_tris) { pb_set_error("pb_emit_beams: pb_set_scene has not been called"); return PB_ERR_STATE; }
   int rc = ensure_device(ctx);
   if (rc != PB_OK) return rc;
-  rc = pb_emit_run(ctx, n_photons, seed);
+  rc = pb_emit_run(ctx, n_photons, seed, false);
   if (rc != PB_OK) return rc;
   if (n_beams_out) *n_beams_out = ctx->n_beams_const + ctx->n_beams_scatt;
+  if (n_segments_out) *n_segments_out = ctx->n_seg;
+  return PB_OK;
+}
+
+int pb_recast_beams(pb_ctx* ctx, uint64_t seed, int* n_scattered_out, int* n_segments_out) {
+  if (!ctx) { pb_set_error("pb_recast_beams: null context"); return PB_ERR_ARG; }
+  if (!ctx->d_tris) { pb_set_error("pb_recast_beams: pb_set_scene has not been called"); return PB_ERR_STATE; }
+  if (!ctx->d_beams) { pb_set_error("pb_recast_beams: pb_emit_beams has not been called"); return PB_ERR_STATE; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  rc = pb_emit_run(ctx, ctx->n_beams_const, seed, true);
+  if (rc != PB_OK) return rc;
+  if (n_scattered_out) *n_scattered_out = ctx->n_beams_scatt;
   if (n_segments_out) *n_segments_out = ctx->n_seg;
   return PB_OK;
 }

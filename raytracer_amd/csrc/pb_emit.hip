@@ -67,6 +67,7 @@ struct EmitParams {
   pb_beam* beams_scatt;
   unsigned int* dropped;      // scattering events dropped because the stack was full
   GridView grid;              // extinction field; used when ctl.heterogeneous
+  const pb_beam* sources;     // re-cast pass: the beams to cast again (one per lane instead of a photon)
 };
 
 // CastPhotons.h:1128-1141
@@ -106,11 +107,13 @@ struct Frame {
 struct BeamSink {
   const EmitParams* p;
   uint32_t photon, order, n_const, n_scatt, off_const, off_scatt;
+  bool scattered_only;        // re-cast pass: pushes into the first list are counted in `order` but not kept
 };
 
 template <bool WRITE>
 PB_DI void push_beam(BeamSink& sink, int parity, V4 start, V4 end, V4 omega_u, float radius, V3 energy,
                      int index_hit, bool ada, bool absorbed) {
+  if (sink.scattered_only && !parity) { sink.order++; return; }
   if (WRITE) {
     pb_beam b;
     b.start[0] = start.x; b.start[1] = start.y; b.start[2] = start.z; b.start[3] = start.w;
@@ -279,8 +282,11 @@ PB_DI void cast_beam(const EmitParams& p, Rng& rng, BeamSink& sink, Frame first,
   }
 }
 
-// CastPhotonBeams, CastPhotons.h:312-368: one photon per lane.
-template <bool WRITE>
+// CastPhotonBeams, CastPhotons.h:312-368: one photon per lane.  RECAST: RecastPhotonBeams (:290-310), one
+// existing beam per lane cast again from its start along its direction; the reference loops over the vector
+// it appends to and never ends, here exactly the beams present on entry are re-cast.  As there, only what
+// lands in the scattered list is kept.
+template <bool WRITE, bool RECAST>
 __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n_photons) return;
@@ -290,8 +296,21 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) 
   rng.k0 = (uint32_t)p.seed; rng.k1 = (uint32_t)(p.seed >> 32);
   BeamSink sink;
   sink.p = &p; sink.photon = (uint32_t)i; sink.order = 0; sink.n_const = 0; sink.n_scatt = 0;
-  sink.off_const = WRITE ? p.off_const[i] : 0u;
+  sink.off_const = (WRITE && !RECAST) ? p.off_const[i] : 0u;
   sink.off_scatt = WRITE ? p.off_scatt[i] : 0u;
+  sink.scattered_only = RECAST;
+  if (RECAST) {
+    const pb_beam b = p.sources[i];
+    const V3 d = normalize3(v3(b.end[0] - b.start[0], b.end[1] - b.start[1], b.end[2] - b.start[2]));
+    Frame f;
+    f.origin = v4(b.start[0], b.start[1], b.start[2], b.start[3]);
+    f.direction = v4(d.x, d.y, d.z, 1.0f);
+    f.energy = v3(b.energy[0], b.energy[1], b.energy[2]);
+    f.bounce = 0; f.parity = 0; f.stage = 0; f.ada = (b.flags & 1u) != 0;
+    cast_beam<WRITE>(p, rng, sink, f, v4(b.omega_u[0], b.omega_u[1], b.omega_u[2], b.omega_u[3]), b.radius);
+    if (!WRITE) { p.cnt_const[i] = 0u; p.cnt_scatt[i] = sink.n_scatt; }
+    return;
+  }
 
   const V4 light = v4(C.light_position[0], C.light_position[1], C.light_position[2], C.light_position[3]);
   const V4 origin = mul4(p.matrix, light);
@@ -476,7 +495,9 @@ struct TmpBuffers {
 
 }  // namespace
 
-int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
+int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
+  // recast: n_photons is the number of beams of the first list, which are kept and cast again
+  pb_beam* old_beams = recast ? ctx->d_beams : nullptr;
   if (ctx->ctl.heterogeneous && !ctx->d_grid) { pb_set_error("pb_emit_beams: HETEROGENEOUS needs pb_set_grid first"); return PB_ERR_STATE; }
   hipStream_t s = ctx->stream;
   PB_HIP(hipEventRecord(ctx->ev[6], s));
@@ -502,8 +523,12 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
   ep.cnt_const = cnt_const; ep.cnt_scatt = cnt_scatt; ep.off_const = off_const; ep.off_scatt = off_scatt;
   ep.dropped = totals + 3;
   ep.grid.z = ctx->d_grid; ep.grid.side = ctx->grid_side;
+  ep.sources = old_beams;
   const int blocks = (n_photons + EMIT_THREADS - 1) / EMIT_THREADS;
-  if (n_photons > 0) hipLaunchKernelGGL(emit_kernel<false>, dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+  if (n_photons > 0) {
+    if (recast) hipLaunchKernelGGL((emit_kernel<false, true>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+    else hipLaunchKernelGGL((emit_kernel<false, false>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+  }
   PB_HIP(hipGetLastError());
   int rc = pb_exclusive_scan_u32(cnt_const, off_const, n_photons, totals + 0, scan_tmp, s);
   if (rc != PB_OK) return rc;
@@ -512,15 +537,27 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed) {
   uint32_t h_tot[4] = {0, 0, 0, 0};
   PB_HIP(hipMemcpyAsync(h_tot, totals, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, s));
   PB_HIP(hipStreamSynchronize(s));
-  const int nc = (int)h_tot[0], ns = (int)h_tot[1], nb = nc + ns;
+  const int nc = recast ? n_photons : (int)h_tot[0], ns = (int)h_tot[1], nb = nc + ns;
 
-  if (ctx->d_beams) { PB_HIP(hipFree(ctx->d_beams)); ctx->d_beams = nullptr; }
-  ctx->n_beams_const = 0; ctx->n_beams_scatt = 0;
-  PB_HIP(hipMalloc(&ctx->d_beams, sizeof(pb_beam) * (size_t)(nb > 0 ? nb : 1)));
-  ep.beams_const = ctx->d_beams; ep.beams_scatt = ctx->d_beams + nc;
+  struct BeamHolder {                    // frees the new list if an error returns before it is adopted
+    pb_beam* p = nullptr;
+    ~BeamHolder() { if (p) (void)hipFree(p); }
+  } holder;
+  PB_HIP(hipMalloc(&holder.p, sizeof(pb_beam) * (size_t)(nb > 0 ? nb : 1)));
+  pb_beam* new_beams = holder.p;
+  if (recast && nc > 0)
+    PB_HIP(hipMemcpyAsync(new_beams, old_beams, sizeof(pb_beam) * (size_t)nc, hipMemcpyDeviceToDevice, s));
+  ep.beams_const = new_beams; ep.beams_scatt = new_beams + nc;
   PB_HIP(hipMemsetAsync(totals + 3, 0, sizeof(uint32_t), s));   // the counting pass reported the same drops
-  if (n_photons > 0) hipLaunchKernelGGL(emit_kernel<true>, dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+  if (n_photons > 0) {
+    if (recast) hipLaunchKernelGGL((emit_kernel<true, true>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+    else hipLaunchKernelGGL((emit_kernel<true, false>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+  }
   PB_HIP(hipGetLastError());
+  PB_HIP(hipStreamSynchronize(s));     // the old list is read by the copy and by the re-cast lanes
+  if (ctx->d_beams) PB_HIP(hipFree(ctx->d_beams));
+  ctx->d_beams = new_beams;
+  holder.p = nullptr;
   ctx->n_beams_const = nc; ctx->n_beams_scatt = ns;
 
   // segments

@@ -230,7 +230,7 @@ struct pb_ctx {
 int pb_ensure_segment_capacity(pb_ctx* ctx, int n);
 int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s);
 int pb_default_mode(const pb_ctx* ctx);
-int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed);
+int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast);
 int pb_lbvh_build(pb_ctx* ctx);
 int pb_lbvh_download(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes);
 

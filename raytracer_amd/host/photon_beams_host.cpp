@@ -132,6 +132,47 @@ AABB CastPhotonBeams(int number, std::vector<PhotonBeam>& beams_const, std::vect
   return root;
 }
 
+namespace {
+void beams_to_host(const std::vector<pb_beam>& src, size_t from, size_t to, std::vector<PhotonBeam>& out) {
+  for (size_t i = from; i < to; ++i) {
+    const pb_beam& b = src[i];
+    PhotonBeam o;
+    o.start = v4(b.start); o.end = v4(b.end); o.omega_u = v4(b.omega_u); o.omega_v = v4(b.omega_u);
+    o.ada_width = (b.flags & 1u) != 0; o.offset = 0.0f; o.radius = b.radius;
+    o.energy = dvec3{b.energy[0], b.energy[1], b.energy[2]};
+    o.index_hit = b.index_hit; o.absorbed = (b.flags & 4u) != 0; o.scattered = (b.flags & 2u) != 0;
+    out.push_back(o);
+  }
+}
+unsigned long long g_recasts = 0;
+}  // namespace
+
+AABB RecastPhotonBeams(std::vector<PhotonBeam>&, std::vector<PhotonBeam>& beams_scattered, const mat4&,
+                       const std::vector<Triangle>&) {
+  pb_ctx* ctx = context();
+  if (control.heterogeneous) upload_grid(ctx, GRID);
+  int n_scatt = 0, n_segs = 0;
+  // a new random stream per call, as the reference's generator simply runs on
+  check(pb_recast_beams(ctx, control.seed + 0x9E3779B97F4A7C15ull * ++g_recasts, &n_scatt, &n_segs), "pb_recast_beams");
+  check(pb_beam_counts(ctx, &g_n_const, &g_n_scatt), "pb_beam_counts");
+  g_beams.resize((size_t)(g_n_const + g_n_scatt > 0 ? g_n_const + g_n_scatt : 1));
+  int got = 0;
+  check(pb_download_beams(ctx, g_beams.data(), (int)g_beams.size(), &got), "pb_download_beams");
+  g_beams.resize((size_t)got);
+  g_segs.resize((size_t)(n_segs > 0 ? n_segs : 1));
+  check(pb_download_segments(ctx, g_segs.data(), (int)g_segs.size(), &got), "pb_download_segments");
+  g_segs.resize((size_t)got);
+  g_bound_calls = 0;
+  beams_scattered.clear();
+  beams_to_host(g_beams, (size_t)g_n_const, g_beams.size(), beams_scattered);
+  float lo[3], hi[3];
+  check(pb_get_root_box(ctx, lo, hi), "pb_get_root_box");
+  AABB root;
+  root.min = vec4{lo[0], lo[1], hi[2], 1}; root.max = vec4{hi[0], hi[1], lo[2], 1};
+  root.mid = vec4{(root.min.x + root.max.x) / 2.0f, (root.min.y + root.max.y) / 2.0f, (root.min.z + root.max.z) / 2.0f, 1};
+  return root;
+}
+
 void BoundPhotonBeams(std::vector<PhotonBeam>& beams, std::vector<PhotonSeg>& items, const std::vector<Triangle>&) {
   // segments of the const list come first; PhotonSeg.id restarts at 0 for the scattered list (CastPhotons.h:227)
   size_t split = g_segs.size();
@@ -254,6 +295,14 @@ void DrawStandard(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>)
   pb_ctx* ctx = context();
   std::vector<float> rgb((size_t)scr->width * scr->height * 3);
   check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_721, /*screen bins*/ 2, rgb.data()), "pb_render");
+  check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
+}
+
+void Draw(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, std::vector<PhotonSeg>&) {
+  pb_ctx* ctx = context();
+  const int mode = control.one_dimensional ? (control.heterogeneous ? PB_MODE_73HET : PB_MODE_73) : PB_MODE_721;
+  std::vector<float> rgb((size_t)scr->width * scr->height * 3);
+  check(pb_render(ctx, 0, 0, scr->width, scr->height, mode, /*screen bins*/ 2, rgb.data()), "pb_render");
   check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
 }
 

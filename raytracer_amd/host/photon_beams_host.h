@@ -63,6 +63,12 @@ void TransformationMatrix(mat4& M);                                             
 
 AABB CastPhotonBeams(int number, std::vector<PhotonBeam>& beams_const, std::vector<PhotonBeam>& beams_scattered,
                      const mat4& matrix, const std::vector<Triangle>& triangles);   // CastPhotons.h:99-103
+// CastPhotons.h:290-310 as ProduceStopMotion uses it (skeleton.cpp:321-322): casts the beams of the first list of
+// the last CastPhotonBeams again through the current GRID and rebuilds `beams_scattered`; `beams_const` (the
+// caller's copy) is left as it is, as the reference discards what it appends to it.  The reference's loop
+// runs over the vector it appends to and does not terminate; exactly the beams present on entry are re-cast.
+AABB RecastPhotonBeams(std::vector<PhotonBeam>& beams_const, std::vector<PhotonBeam>& beams_scattered,
+                       const mat4& matrix, const std::vector<Triangle>& triangles);
 // Appends the segments of `beams` (the list of that size returned by the last CastPhotonBeams).
 void BoundPhotonBeams(std::vector<PhotonBeam>& beams, std::vector<PhotonSeg>& items,
                       const std::vector<Triangle>& triangles);                       // CastPhotons.h:107
@@ -88,6 +94,10 @@ void KillSDL(screen* s);                                                        
 // uses its global `root`.
 void DrawStandard(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scatt);
 
+// skeleton.cpp:414-473 without ADAPTIVE and SHORT_VIEW: the estimator follows control.one_dimensional and
+// control.heterogeneous as BeamRadiance does (BeamRadiance.h:508-541).
+void Draw(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scattered,
+          std::vector<PhotonSeg>& items);
 // One frame of skeleton.cpp:367-412 (BVHBeamRadianceHet with Integral_73Het); the NodeGen argument is
 // unused there as well.
 void DrawHet(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scattered, NodeGen*);

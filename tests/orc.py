@@ -252,6 +252,10 @@ class Oracle:
         n = self.control.photon_number if number is None else number
         return self.L.orc_cast_photon_beams(self.h, C.c_int(n), C.c_int(rng_kind))
 
+    def recast_photon_beams(self, rng_kind=1, seed=42):
+        self.L.orc_recast_photon_beams.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        return self.L.orc_recast_photon_beams(self.h, C.c_int(rng_kind), C.c_uint64(seed))
+
     def beam_counts(self):
         a = C.c_int(0); b = C.c_int(0)
         self.L.orc_beam_counts(self.h, C.byref(a), C.byref(b))

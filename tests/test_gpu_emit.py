@@ -110,3 +110,45 @@ def test_render_of_gpu_emitted_set_matches_oracle(pb):
     assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), err.max()
     assert np.sqrt((err ** 2).mean()) <= 1e-4
     assert ref.max() > 1.0 and cnt["valid_hits"] > 10000
+
+
+@pytest.mark.parametrize("het", [0, 1])
+def test_recast_matches_oracle(pb, het):
+    """RecastPhotonBeams + BoundPhotonBeams as ProduceStopMotion chains them (skeleton.cpp:312-324): the first
+    list is cast again through a changed medium, the scattered list and all segments are rebuilt.  Oracle and
+    GPU both re-cast exactly the beams present on entry (the reference's loop does not terminate)."""
+    kw = dict(photon_number=1200, bounces=1)
+    if het:
+        kw.update(heterogeneous=1, one_dimensional=1)
+    o = orc.Oracle(orc.control_defaults(**kw))
+    if het:
+        o.make_grid(27, -3.0, 0.016)
+    o.cast_photon_beams(rng_kind=1)
+    n_const0, _ = o.beam_counts()
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        if het:
+            ctx.set_grid(*pb.make_grid(time=0.016))
+        ctx.cast_photon_beams()
+        first = ctx.download_beams()[:n_const0].copy()
+        assert ctx.beam_counts()[0] == n_const0
+        for seed, time in ((1001, 0.5), (1002, 1.25)):
+            if het:
+                sigma, side = o.make_grid(27, -3.0, time)
+                ctx.set_grid(*pb.make_grid(time=time))
+            n_sc = o.recast_photon_beams(1, seed)
+            o.bound_photon_beams()
+            ob, oseg = o.beams(), o.export_segments(tree=False)
+            g_sc, g_seg = ctx.recast_photon_beams(seed)
+            gb, gseg = ctx.download_beams(), ctx.download_segments()
+            assert ctx.beam_counts() == (n_const0, n_sc) and g_sc == n_sc
+            assert gb[:n_const0].tobytes() == first.tobytes()          # the first list is kept as it was
+            for f in ("photon", "order", "flags", "index_hit"):
+                assert np.array_equal(gb[f], ob[f]), f
+            for f in ("start", "end"):
+                d = np.abs(gb[f] - ob[f]).max(1)
+                assert (d <= 2e-5).mean() > 0.98 and d.max() < 2e-2, (f, d.max())
+            rel = np.abs(gb["energy"] - ob["energy"]) / np.abs(ob["energy"])
+            assert (rel <= 2e-5).mean() > 0.97 and rel.max() < 2e-2
+            assert abs(g_seg - len(oseg)) <= 0.01 * len(oseg) + 4 and g_seg == len(gseg)
+            assert n_sc > 50

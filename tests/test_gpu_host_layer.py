@@ -77,3 +77,27 @@ def test_heterogeneous_run_through_reference_named_functions(tmp_path):
     assert f"Beams size: {n_beams}" in r.stdout and f"Segment size: {n_segs}" in r.stdout
     assert np.array_equal(img, ref)
     assert (img & 0xFF).max() > 20
+
+
+def test_stop_motion_through_reference_named_functions(tmp_path):
+    """ProduceStopMotion (skeleton.cpp:265-328): three frames, the medium replaced and the beams re-cast between
+    them.  The first frame is the plain heterogeneous run; later frames keep the first beam list and differ."""
+    exe = os.path.join(ROOT, "examples", "stop_motion_headless")
+    assert os.path.exists(exe), "examples/stop_motion_headless is not built (make -C raytracer_amd/csrc)"
+    prefix = str(tmp_path / "shot_")
+    r = subprocess.run([exe, "600", "128", "16", "19", prefix, "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=180)
+    assert r.returncode == 0, r.stdout
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("frame ")]
+    assert len(lines) == 3
+    imgs = [read_bmp32(f"{prefix}{i}_.bmp") for i in (16, 17, 18)]
+    assert all(im.shape == (128, 128) and (im & 0xFF).max() > 10 for im in imgs)
+    assert not np.array_equal(imgs[0], imgs[1]) and not np.array_equal(imgs[1], imgs[2])
+    import raytracer_amd as pb
+    kw = dict(photon_number=600, screen_width=128, screen_height=128, heterogeneous=1, one_dimensional=1)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.set_grid(*pb.make_grid(time=0.016))
+        ctx.cast_photon_beams()
+        ref0 = pb.quantise_argb(ctx.draw(mode=pb.MODE_73HET, cull="bins"))
+    assert np.array_equal(imgs[0], ref0)
