@@ -121,10 +121,15 @@ typedef struct pb_stats {
 
 typedef struct pb_ctx pb_ctx;
 
-enum { PB_MODE_721 = 721,      /* BeamRadianceStandard + Integral_721 (BeamRadiance.h:415-469, :86-110)             */
+enum { PB_MODE_DEFAULT = 0,    /* what Control selects: GENERIC if adaptive, else 73HET / 73 / 721 by one_dimensional
+                                  and heterogeneous (the dispatch of skeleton.cpp:225-262)                           */
+       PB_MODE_721 = 721,      /* BeamRadianceStandard + Integral_721 (BeamRadiance.h:415-469, :86-110)             */
        PB_MODE_73HET = 73,     /* BVHBeamRadianceHet + Integral_73Het (:356-414, :211-288); needs pb_set_grid       */
-       PB_MODE_73 = 730 };     /* BeamRadiance with ONE_DIMENSIONAL in a homogeneous medium: Integral_73 (:510-524,
+       PB_MODE_73 = 730,       /* BeamRadiance with ONE_DIMENSIONAL in a homogeneous medium: Integral_73 (:510-524,
                                   :112-209 with HETEROGENEOUS false)                                                  */
+       PB_MODE_GENERIC = 471 };/* BeamRadiance as written (:471-555): a segment with ada_width set is a cone (HitCone,
+                                  Intersections.h:145-305, + Integral_721_ada, BeamRadiance.h:63-84), any other a
+                                  cylinder with Integral_73 if control.one_dimensional, else Integral_721             */
 
 /* Control.h:4-50 defaults. */
 void pb_control_defaults(pb_control* c);

@@ -105,6 +105,36 @@ def main():
     out["rot_c"], out["rot_w"] = c, w
     out["rot_m"] = np.stack([orc.find_rotation_matrix(c[i], w[i], use_ref=True) for i in range(n)])
 
+    # HitCone: the adaptive-width beams of configuration 1 (one cone per beam, apex at the beam's start),
+    # a share of them cut into a frustum (seg.start moved along the axis) as the heterogeneous split does
+    oa = orc.Oracle(orc.control_defaults(adaptive=1))
+    oa.cast_photon_beams(); oa.bound_photon_beams()
+    cones = oa.export_segments(tree=False)
+    cones = cones[(cones["flags"] & 1) == 1]
+    n = 6000
+    pick = cones[rng.integers(0, len(cones), n)]
+    s0 = np.ones((n, 4), np.float32); s1 = np.ones((n, 4), np.float32); so = np.ones((n, 4), np.float32)
+    s0[:, :3] = pick["start"]; s1[:, :3] = pick["end"]; so[:, :3] = pick["orig_start"]
+    cut = rng.random(n) < 0.3
+    f = rng.uniform(0.1, 0.8, (n, 1)).astype(np.float32)
+    s0[cut, :3] = (so[:, :3] + f * (s1[:, :3] - so[:, :3]))[cut]
+    rad = pick["radius"].astype(np.float32)
+    u = rng.uniform(-0.15, 1.15, (n, 1)).astype(np.float32)
+    u[rng.random(n) < 0.15] = 0.0
+    u[rng.random(n) < 0.15] = 1.0
+    spread = (rad[:, None] * np.clip(u, 0.05, 1.0)).astype(np.float32)
+    target = so[:, :3] + u * (s1[:, :3] - so[:, :3]) + rng.normal(size=(n, 3)).astype(np.float32) * spread
+    dirs = np.ones((n, 4), np.float32)
+    dirs[:, :3] = target
+    dirs = (dirs / np.sqrt((dirs * dirs).sum(1, keepdims=True))).astype(np.float32)
+    start = np.zeros((n, 4), np.float32); start[:, 3] = 1
+    res = np.stack([orc.hit_cone(start[i], dirs[i], s0[i], s1[i], so[i], float(rad[i]), use_ref=True)
+                    for i in range(n)])
+    out["co_start"], out["co_dir"], out["co_s0"], out["co_s1"], out["co_so"], out["co_radius"] = \
+        start, dirs, s0, s1, so, rad
+    out["co_out"] = res
+    print("cone true", int(res[:, 0].sum()), "cone valid", int(res[:, 1].sum()))
+
     dst = os.path.join(orc.ROOT, "tests", "golden", "ref_primitives.npz")
     np.savez_compressed(dst, **out)
     cy = out["cy_out"]

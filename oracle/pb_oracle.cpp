@@ -333,6 +333,96 @@ static bool HitCylinder(vec4 start, vec4 dir, const PhotonSeg& seg, CylIntersect
   return first_inte;
 }
 
+// Intersections.h:145-305.  The quadric is the double cone of half-angle tan_theta (the reference takes the
+// cosine and sine of the tangent itself) about the y axis of the frame in which orig_start is the origin and
+// orig_start -> end is the unit y axis; `min` is the y of seg.start in that frame.  pow( float, 2 ) promotes to
+// double: the three coefficients are double expressions rounded to float once.  second_hit is left unset by
+// the reference where th2 <= 0; the zero used here is only read when such a hit is also `valid`.
+static bool HitCone(vec4 start, vec4 dir, const PhotonSeg& seg, CylIntersection& isect) {
+  bool first_inte = false;
+  vec3 l_unit_dir = normalize(xyz(dir));
+  vec4 d4 = seg.end - seg.orig_start;
+  vec3 difference = xyz(d4);
+  float len = length(difference);
+  vec3 w_unit_dir = normalize(V3(0.0f, len, 0.0f));
+  float S_inv = 1 / len;
+  vec3 c_unit_dir = difference * S_inv;
+  mat3 R_inv = findRotationMatrix(c_unit_dir, w_unit_dir);
+  vec3 T_inv = -((R_inv * xyz(seg.orig_start)) * S_inv);
+  vec3 origin_prime = (R_inv * (xyz(start) * S_inv)) + T_inv;
+  vec3 dir_prime = R_inv * l_unit_dir;
+  float height = length(d4);
+  float r1 = seg.radius * S_inv;
+  float tan_theta = r1 / height;
+  float min = (((R_inv * xyz(seg.start)) * S_inv) + T_inv).y;
+  vec3 first_hit = V3(0, 0, 0), second_hit = V3(0, 0, 0);
+  float t0 = -1, t1 = -1;
+  const double c2 = (double)std::cos(tan_theta) * (double)std::cos(tan_theta);
+  const double s2 = (double)std::sin(tan_theta) * (double)std::sin(tan_theta);
+  float a = (float)(c2 * (dir_prime.x * dir_prime.x + dir_prime.z * dir_prime.z) - s2 * dir_prime.y * dir_prime.y);
+  float b = (float)(c2 * (2 * origin_prime.x * dir_prime.x + 2 * origin_prime.z * dir_prime.z) -
+                    s2 * 2 * origin_prime.y * dir_prime.y);
+  float c = (float)(c2 * (origin_prime.x * origin_prime.x + origin_prime.z * origin_prime.z) -
+                    s2 * origin_prime.y * origin_prime.y);
+  float b24ac = b * b - 4 * a * c;
+  if (b24ac < 0) return false;
+  float sq = sqrtf(b24ac);
+  t0 = (-b + sq) / (2 * a);
+  t1 = (-b - sq) / (2 * a);
+  if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+  float y0 = origin_prime.y + t0 * dir_prime.y;
+  float y1 = origin_prime.y + t1 * dir_prime.y;
+  if (y0 < min) {
+    if (y1 < min) return false;
+    float th1 = t0 + (t1 - t0) * (y0 - min) / (y0 - y1);
+    if (th1 <= 0) return false;
+    first_hit = origin_prime + (dir_prime * th1);
+    first_inte = true;
+    if (y1 <= 1) second_hit = origin_prime + (dir_prime * t1);
+    else {
+      float th2 = t1 + (t1 - t0) * (y1 - 1) / (y0 - y1);
+      if (th2 > 0) second_hit = origin_prime + (dir_prime * th2);
+    }
+  } else if (y0 >= min && y0 <= 1) {
+    if (t0 <= 0) return false;
+    first_hit = origin_prime + (dir_prime * t0);
+    first_inte = true;
+    if (y1 >= min) {
+      if (y1 <= 1) second_hit = origin_prime + (dir_prime * t1);
+      else {
+        float th2 = t1 + (t1 - t0) * (y1 - 1) / (y0 - y1);
+        if (th2 > 0) second_hit = origin_prime + (dir_prime * th2);
+      }
+    } else {
+      float th2 = t0 + (t1 - t0) * (y0 - min) / (y0 - y1);
+      if (th2 > 0) second_hit = origin_prime + (dir_prime * th2);
+    }
+  } else if (y0 > 1) {
+    if (y1 > 1) return false;
+    float th = t0 + (t1 - t0) * (y0 - 1) / (y0 - y1);
+    if (th <= 0) return false;
+    first_hit = origin_prime + (dir_prime * th);
+    first_inte = true;
+    if (y1 >= 0) second_hit = origin_prime + (dir_prime * t1);       // :275 compares with 0, not min
+    else {
+      float th2 = t0 + (t1 - t0) * (y0 - min) / (y0 - y1);
+      if (th2 > 0) second_hit = origin_prime + (dir_prime * th2);
+    }
+  }
+  if ((t0 > 0) && (t1 > 0) && (t1 > t0)) {
+    isect.valid = true;
+    mat3 R = inverse(R_inv);
+    isect.entry_point = (R * (first_hit - T_inv)) / S_inv;
+    isect.exit_point = (R * (second_hit - T_inv)) / S_inv;
+    float tb0 = length(seg.start - seg.orig_start);
+    isect.tb_minus = tb0 + (first_hit.y / S_inv);
+    isect.tb_plus = tb0 + (second_hit.y / S_inv);
+    isect.tc_minus = length(isect.entry_point);
+    isect.tc_plus = length(isect.exit_point);
+  } else isect.valid = false;
+  return first_inte;
+}
+
 // CastPhotons.h:1143-1146
 static double Transmittance(double length, double ext) { return std::exp(-ext * length); }
 
@@ -427,6 +517,26 @@ static double Integral_721(const PhotonSeg& s, const CylIntersection& i, float e
   float den_f = std::exp(extinction * (i.tc_minus + i.tb_minus)) * extinction * (std::fabs(cos_theta) - 1);
   double numerator = num_f, denominator = den_f;
   return numerator / denominator;
+}
+
+// BeamRadiance.h:63-84 — the cone estimator: a Riemann sum in steps of 0.001 along the view ray between the two
+// hits, the beam width at the matching distance along the beam growing linearly from the apex.
+static double Integral_721_ada(const PhotonSeg& s, const CylIntersection& i, float extinction, float scattering_c,
+                               vec4 dir) {
+  vec3 beam_dir = normalize(xyz(s.end) - xyz(s.start));
+  vec3 camera_dir = normalize(xyz(dir));
+  double cos_theta = dot(beam_dir, -camera_dir);
+  double length_const = length(s.orig_start - s.end);
+  double integrand = 0;
+  double dt_c = 0.001;
+  for (double tc = i.tc_minus; tc < i.tc_plus; tc = tc + dt_c) {
+    double tb = i.tb_minus - (std::fabs(cos_theta) * (tc - i.tc_minus));
+    double current_r = (s.radius / length_const) * tb;
+    double constant = Transmittance(tb, extinction);
+    double transmitted = Transmittance(tc, extinction) * constant * (scattering_c / std::pow(current_r, 2)) * dt_c;
+    integrand += transmitted;
+  }
+  return integrand;
 }
 
 // BeamRadiance.h:211-288
@@ -954,7 +1064,7 @@ static inline bool box_gate(const AABB& box, const RayCtx& r) {      // BeamRadi
   return hit_distance <= r.max_distance;
 }
 
-struct Medium { float extinction_c, scattering_c; const Grid* grid; };
+struct Medium { float extinction_c, scattering_c; const Grid* grid; bool one_dimensional = false; };
 
 // Leaf body of BeamRadianceStandard (BeamRadiance.h:436-456) / BVHBeamRadianceHet (:378-398).
 static inline void leaf_segment(const PhotonSeg& seg, const dvec3& energy, const RayCtx& r, int mode,
@@ -962,11 +1072,23 @@ static inline void leaf_segment(const PhotonSeg& seg, const dvec3& energy, const
   CylIntersection isect;
   isect.valid = false;
   cnt.cyl_calls++;
+  const double phase_f = 1 / (4 * PI_REF);
+  if (mode == PB_MODE_GENERIC && seg.ada_width) {                  // BeamRadiance.h:488-507
+    if (HitCone(r.start, r.dir, seg, isect)) {
+      cnt.cyl_true++;
+      if (isect.valid) {
+        cnt.valid_hits++;
+        double _int = Integral_721_ada(seg, isect, med.extinction_c, med.scattering_c, r.dir);
+        current = current + (energy * phase_f) * _int;
+      }
+    }
+    return;
+  }
+  if (mode == PB_MODE_GENERIC) mode = med.one_dimensional ? PB_MODE_73 : PB_MODE_721;   // :508-541
   if (HitCylinder(r.start, r.dir, seg, isect)) {
     cnt.cyl_true++;
     if (isect.valid) {
       cnt.valid_hits++;
-      double phase_f = 1 / (4 * PI_REF);
       if (mode == PB_MODE_721) {
         double _int = Integral_721(seg, isect, med.extinction_c, r.dir);
         double rad = med.scattering_c / (PI_REF * ((double)seg.radius * (double)seg.radius));
@@ -1087,13 +1209,14 @@ int orc_hit_bounding_box(const float bmin[4], const float bmax[4], const float s
   return r ? 1 : 0;
 }
 
-void orc_hit_cylinder(const float start[4], const float dir[4], const float s0[4], const float s1[4],
-                      const float so[4], float radius, float out[12]) {
+static void hit_quadric(bool cone, const float start[4], const float dir[4], const float s0[4], const float s1[4],
+                        const float so[4], float radius, float out[12]) {
   PhotonSeg seg{};
   seg.start = V4(s0[0], s0[1], s0[2], s0[3]); seg.end = V4(s1[0], s1[1], s1[2], s1[3]);
   seg.orig_start = V4(so[0], so[1], so[2], so[3]); seg.radius = radius;
   CylIntersection ci{};
-  bool r = HitCylinder(V4(start[0], start[1], start[2], start[3]), V4(dir[0], dir[1], dir[2], dir[3]), seg, ci);
+  const vec4 st = V4(start[0], start[1], start[2], start[3]), d = V4(dir[0], dir[1], dir[2], dir[3]);
+  bool r = cone ? HitCone(st, d, seg, ci) : HitCylinder(st, d, seg, ci);
   for (int i = 0; i < 12; ++i) out[i] = 0;
   out[0] = r ? 1.f : 0.f;
   if (r) {
@@ -1104,6 +1227,26 @@ void orc_hit_cylinder(const float start[4], const float dir[4], const float s0[4
       out[9] = ci.exit_point.x; out[10] = ci.exit_point.y; out[11] = ci.exit_point.z;
     }
   }
+}
+
+void orc_hit_cylinder(const float start[4], const float dir[4], const float s0[4], const float s1[4],
+                      const float so[4], float radius, float out[12]) {
+  hit_quadric(false, start, dir, s0, s1, so, radius, out);
+}
+
+void orc_hit_cone(const float start[4], const float dir[4], const float s0[4], const float s1[4],
+                  const float so[4], float radius, float out[12]) {
+  hit_quadric(true, start, dir, s0, s1, so, radius, out);
+}
+
+double orc_integral_721_ada(const float s0[4], const float s1[4], const float so[4], float radius, float tb_minus,
+                            float tc_minus, float tc_plus, float extinction, float scattering, const float dir[4]) {
+  PhotonSeg seg{};
+  seg.start = V4(s0[0], s0[1], s0[2], s0[3]); seg.end = V4(s1[0], s1[1], s1[2], s1[3]);
+  seg.orig_start = V4(so[0], so[1], so[2], so[3]); seg.radius = radius;
+  CylIntersection ci{};
+  ci.tb_minus = tb_minus; ci.tc_minus = tc_minus; ci.tc_plus = tc_plus;
+  return Integral_721_ada(seg, ci, extinction, scattering, V4(dir[0], dir[1], dir[2], dir[3]));
 }
 
 void orc_find_rotation_matrix(const float c[3], const float w[3], float m9[9]) {
@@ -1434,7 +1577,7 @@ int orc_render_tree(orc_ctx* c, int x0, int y0, int w, int h, int mode, double* 
   const Oracle& o = c->o;
   if (o.nodes.empty()) return -1;
   const int ssaa = o.ctl.c.ssaa;
-  Medium med{o.extinction_c(), o.scattering_c(), &o.GRID};
+  Medium med{o.extinction_c(), o.scattering_c(), &o.GRID, o.ctl.c.one_dimensional != 0};
   orc_counters total{};
   (void)threads;
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
@@ -1487,7 +1630,7 @@ int orc_render_segments_strided(const pb_control* control, const float* tri_xyz,
   Grid grid;
   if (grid_sigma && side > 1) grid = grid_from_sigma(grid_sigma, side);
   if (mode == PB_MODE_73HET && grid.side_points < 2) return -1;
-  Medium med{ctl.extinction_c(), ctl.c.scattering_c, &grid};
+  Medium med{ctl.extinction_c(), ctl.c.scattering_c, &grid, ctl.c.one_dimensional != 0};
   std::vector<PhotonSeg> ps(n);
   std::vector<AABB> boxes(n);
   std::vector<dvec3> energy(n);

@@ -37,6 +37,13 @@ int  orc_hit_bounding_box(const float box_min[4], const float box_max[4], const 
 /* out[0]=returned bool, out[1]=valid, then tb-,tb+,tc-,tc+, entry xyz, exit xyz (12 floats) */
 void orc_hit_cylinder(const float start[4], const float dir[4], const float seg_start[4],
                       const float seg_end[4], const float seg_orig_start[4], float radius, float out[12]);
+/* HitCone (Intersections.h:145-305), same output layout */
+void orc_hit_cone(const float start[4], const float dir[4], const float seg_start[4],
+                  const float seg_end[4], const float seg_orig_start[4], float radius, float out[12]);
+/* Integral_721_ada (BeamRadiance.h:63-84) */
+double orc_integral_721_ada(const float seg_start[4], const float seg_end[4], const float seg_orig_start[4],
+                            float radius, float tb_minus, float tc_minus, float tc_plus, float extinction,
+                            float scattering, const float dir[4]);
 void orc_find_rotation_matrix(const float c_dir[3], const float w_dir[3], float m9[9]);
 double orc_integral_721(const float seg_start[4], const float seg_end[4], float tb_minus, float tc_minus,
                         float tc_plus, float extinction, const float dir[4]);

@@ -63,17 +63,17 @@ int ref_hit_bounding_box(const float bmin[4], const float bmax[4], const float s
   return r ? 1 : 0;
 }
 
-void ref_hit_cylinder(const float start[4], const float dir[4], const float s0[4], const float s1[4],
-                      const float so[4], float radius, float out[12]) {
+static void hit_quadric(bool cone, const float start[4], const float dir[4], const float s0[4], const float s1[4],
+                        const float so[4], float radius, float out[12]) {
   PhotonSeg seg;
   seg.start = v4(s0);
   seg.end = v4(s1);
   seg.orig_start = v4(so);
   seg.radius = radius;
-  seg.ada_width = false;
+  seg.ada_width = cone;
   CylIntersection ci;
   ci.valid = false;
-  bool r = HitCylinder(v4(start), v4(dir), seg, ci);
+  bool r = cone ? HitCone(v4(start), v4(dir), seg, ci) : HitCylinder(v4(start), v4(dir), seg, ci);
   for (int i = 0; i < 12; ++i) out[i] = 0;
   out[0] = r ? 1.f : 0.f;
   if (r) {
@@ -83,6 +83,16 @@ void ref_hit_cylinder(const float start[4], const float dir[4], const float s0[4
       for (int c = 0; c < 3; ++c) { out[6 + c] = ci.entry_point[c]; out[9 + c] = ci.exit_point[c]; }
     }
   }
+}
+
+void ref_hit_cylinder(const float start[4], const float dir[4], const float s0[4], const float s1[4],
+                      const float so[4], float radius, float out[12]) {
+  hit_quadric(false, start, dir, s0, s1, so, radius, out);
+}
+
+void ref_hit_cone(const float start[4], const float dir[4], const float s0[4], const float s1[4],
+                  const float so[4], float radius, float out[12]) {
+  hit_quadric(true, start, dir, s0, s1, so, radius, out);
 }
 
 void ref_find_rotation_matrix(const float c[3], const float w[3], float m9[9]) {

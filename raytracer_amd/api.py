@@ -14,6 +14,8 @@ _LIB_PATH = os.path.join(_HERE, "lib", "libphoton_beams.so")
 MODE_721 = 721     # BeamRadianceStandard + Integral_721
 MODE_73HET = 73    # BVHBeamRadianceHet + Integral_73Het
 MODE_73 = 730      # BeamRadiance with ONE_DIMENSIONAL, homogeneous medium: Integral_73
+MODE_DEFAULT = 0    # the estimator Control selects
+MODE_GENERIC = 471  # BeamRadiance as written: cones (HitCone + Integral_721_ada) for adaptive-width segments
 
 
 class PhotonBeamsError(RuntimeError):

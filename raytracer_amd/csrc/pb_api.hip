@@ -59,6 +59,7 @@ int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
 namespace {
 
 int default_mode(const pb_ctx* ctx) {
+  if (ctx->ctl.adaptive) return PB_MODE_GENERIC;      // cones exist only in BeamRadiance (BeamRadiance.h:488)
   if (ctx->ctl.heterogeneous && ctx->ctl.one_dimensional) return PB_MODE_73HET;
   return ctx->ctl.one_dimensional ? PB_MODE_73 : PB_MODE_721;
 }
@@ -67,7 +68,7 @@ int default_mode(const pb_ctx* ctx) {
 
 int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
   PB_HIP(hipEventRecord(ctx->ev[2], s));
-  int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA,
+  int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.one_dimensional, ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA,
                                       ctx->d_capB, ctx->d_het, s);
   if (rc != PB_OK) return rc;
   PB_HIP(hipEventRecord(ctx->ev[3], s));
@@ -207,7 +208,10 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
                   float* d_out, hipStream_t s) {
   if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
   if (!ctx->have_segments) { pb_set_error("pb_render: no segment set (pb_upload_segments / pb_emit_beams)"); return PB_ERR_STATE; }
-  if (mode != PB_MODE_721 && mode != PB_MODE_73HET && mode != PB_MODE_73) { pb_set_error("pb_render: mode must be PB_MODE_721, PB_MODE_73 or PB_MODE_73HET"); return PB_ERR_ARG; }
+  if (mode == PB_MODE_DEFAULT) mode = default_mode(ctx);
+  if (mode != PB_MODE_721 && mode != PB_MODE_73HET && mode != PB_MODE_73 && mode != PB_MODE_GENERIC) {
+    pb_set_error("pb_render: mode must be PB_MODE_721, PB_MODE_73, PB_MODE_73HET or PB_MODE_GENERIC"); return PB_ERR_ARG;
+  }
   if (use_lbvh < 0 || use_lbvh > 2) { pb_set_error("pb_render: cull mode must be 0 (scan), 1 (LBVH) or 2 (screen bins)"); return PB_ERR_ARG; }
   if (use_lbvh == 1 && (ctx->lb_n < 0 || ctx->lb_version != ctx->segs_version)) {
     pb_set_error("pb_render: pb_build_lbvh has not been called for this segment set"); return PB_ERR_STATE;
@@ -225,7 +229,11 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.focal = (float)(ctx->ctl.screen_width * ctx->ctl.ssaa);      // rasteriser.h:17
   p.extinction_c = ctx->ctl.absorption_c + ctx->ctl.scattering_c; // Control.h:48
   p.scattering_c = ctx->ctl.scattering_c;
-  p.het = ctx->d_het; p.grid_z = (mode == PB_MODE_73HET) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side;
+  // Integral_73 reads the grid when HETEROGENEOUS is set (BeamRadiance.h:159-188)
+  const bool generic_het = mode == PB_MODE_GENERIC && ctx->ctl.one_dimensional && ctx->ctl.heterogeneous;
+  p.het = ctx->d_het; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side;
+  p.one_dimensional = ctx->ctl.one_dimensional;
+  if (generic_het && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_GENERIC with one_dimensional and heterogeneous set needs pb_set_grid"); return PB_ERR_STATE; }
   if (mode == PB_MODE_73HET && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_73HET needs pb_set_grid"); return PB_ERR_STATE; }
   p.x0 = x0; p.y0 = y0; p.out_w = out_w; p.out_h = out_h; p.strip_stride = strip_stride;
   p.tiles_x = (out_w + 7) / 8; p.tiles_y = (out_h + 7) / 8;

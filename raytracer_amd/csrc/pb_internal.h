@@ -40,7 +40,8 @@ struct __attribute__((aligned(64))) SegFrame {
   float len;       // 13      |end-start|
   float tb0;       // 14      |start-orig_start|
   uint32_t qflags; // 15      bit i: origin inside slab i (MIDDLE); bit 3: origin inside the box;
-                   //         bit 4: the gate box contains the segment's cylinder
+                   //         bit 4: the gate box contains the segment's cylinder; bit 5: the record is a cone's
+                   //         (HitCone, Intersections.h:145-305): frame about orig_start, c4 = 4 c of :196-200
   double W[3];     // 16..21  energy*(1/(4 PI))*(sigma_s/(PI r^2)) (721) or energy*(1/(4 PI)) (73het)
   float lo[3];     // 22..24  gate box, min_b of HitBoundingBox
   float hi[3];     // 25..27  max_b
@@ -50,7 +51,7 @@ struct __attribute__((aligned(64))) SegFrame {
   float ox, oz;    // 41,42   T_inv.x, T_inv.z
   float bdir[3];   // 43..45  normalize(end-start)
   float radius;    // 46
-  float pad;
+  float ymin;      // 47      cone records: y of seg.start in the cone's frame (Intersections.h:175); else 0
 };
 static_assert(sizeof(SegFrame) == 192, "SegFrame layout");
 
@@ -64,6 +65,14 @@ struct __attribute__((aligned(32))) HetFrame {
   float radius;
 };
 static_assert(sizeof(HetFrame) == 32, "HetFrame layout");
+
+// A cone record's slot in the same array: cos^2 and sin^2 of HitCone's tan_theta (Intersections.h:184-200),
+// each the square, in double, of the float cosine / sine.
+struct __attribute__((aligned(32))) ConeFrame {
+  double c2, s2;
+  float pad[4];
+};
+static_assert(sizeof(ConeFrame) == 32, "ConeFrame layout");
 
 // LBVH internal node as the tile traversal reads it: both child boxes inline, 64 B.
 // child >= 0: internal node index; child < 0: leaf, ~child = position in Morton order.
@@ -93,7 +102,8 @@ struct RenderParams {
   float focal;             // rasteriser.h:17
   float extinction_c;      // Control.h:48
   float scattering_c;      // Control.h:47
-  const HetFrame* het;     // per segment, mode 73 only
+  const HetFrame* het;     // per segment: Integral_73/73Het inputs, or a ConeFrame where qflags bit 5 is set
+  int one_dimensional;     // ONE_DIMENSIONAL, read by PB_MODE_GENERIC
   const float* grid_z;     // sigma_t field (side*side) or nullptr
   int grid_side;
   // geometry of this launch: tile (tx, k) covers pixels x = x0 + 8*tx + lx,
@@ -246,7 +256,7 @@ int pb_lbvh_download(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes
 // launchers implemented in the kernel translation units
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matrix16, TriPrep* d_out,
                             float4* d_screen_box, hipStream_t s);
-int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float scattering_c, SegFrame* d_frames,
+int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int one_dimensional, float scattering_c, SegFrame* d_frames,
                                float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s);
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);

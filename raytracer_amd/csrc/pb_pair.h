@@ -257,6 +257,114 @@ PB_DI int eval_pair_73het(const SegFrame& f, const HetFrame& hf, V3 seg_start, V
   return 2;
 }
 
+// HitCone (Intersections.h:145-305) with the per-segment frame prepared (about orig_start), then the segment's
+// gate box.  Same return convention as hit_cylinder_exact.  pow( float, 2 ) promotes: the coefficients are
+// double expressions of the float terms, rounded to float once.
+PB_DI int hit_cone_exact(const SegFrame& f, const ConeFrame& cf, const Ray& r, CylHit& h) {
+  h.first_inte = false;
+  const V3 l = r.l;
+  const float dpx = f.Rinv[0] * l.x + f.Rinv[3] * l.y + f.Rinv[6] * l.z;
+  const float dpy = f.Rinv[1] * l.x + f.Rinv[4] * l.y + f.Rinv[7] * l.z;
+  const float dpz = f.Rinv[2] * l.x + f.Rinv[5] * l.y + f.Rinv[8] * l.z;
+  const float ox = f.ox, oy = f.oy, oz = f.oz, ymin = f.ymin;
+  const float a = (float)(cf.c2 * (double)(dpx * dpx + dpz * dpz) - (cf.s2 * (double)dpy) * (double)dpy);
+  const float b = (float)(cf.c2 * (double)(f.ox2 * dpx + f.oz2 * dpz) - ((cf.s2 * 2.0) * (double)oy) * (double)dpy);
+  const float b24ac = b * b - a * f.c4;
+  if (b24ac < 0) return 0;
+  const float sq = pb_sqrt(b24ac);
+  float t0 = (-b + sq) / (2 * a);
+  float t1 = (-b - sq) / (2 * a);
+  if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+  const float y0 = oy + t0 * dpy;
+  const float y1 = oy + t1 * dpy;
+  float thf = 0.0f, ths = 0.0f;
+  bool have_second = false;
+  if (y0 < ymin) {
+    if (y1 < ymin) return 1;
+    thf = t0 + (t1 - t0) * (y0 - ymin) / (y0 - y1);
+    if (thf <= 0) return 1;
+    if (y1 <= 1) { ths = t1; have_second = true; }
+    else { float th2 = t1 + (t1 - t0) * (y1 - 1) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
+  } else if (y0 >= ymin && y0 <= 1) {
+    if (t0 <= 0) return 1;
+    thf = t0;
+    if (y1 >= ymin) {
+      if (y1 <= 1) { ths = t1; have_second = true; }
+      else { float th2 = t1 + (t1 - t0) * (y1 - 1) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
+    } else { float th2 = t0 + (t1 - t0) * (y0 - ymin) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
+  } else if (y0 > 1) {
+    if (y1 > 1) return 1;
+    thf = t0 + (t1 - t0) * (y0 - 1) / (y0 - y1);
+    if (thf <= 0) return 1;
+    if (y1 >= 0) { ths = t1; have_second = true; }                  // :275 compares with 0, not with min
+    else { float th2 = t0 + (t1 - t0) * (y0 - ymin) / (y0 - y1); if (th2 > 0) { ths = th2; have_second = true; } }
+  } else return 1;
+  h.first_inte = true;
+  if (!((t0 > 0) && (t1 > 0) && (t1 > t0))) return 1;
+  if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
+  const float fx = ox + dpx * thf, fy = oy + dpy * thf, fz = oz + dpz * thf;
+  const float sx = have_second ? ox + dpx * ths : 0.0f;
+  const float sy = have_second ? oy + dpy * ths : 0.0f;
+  const float sz = have_second ? oz + dpz * ths : 0.0f;
+  const float ux = fx - ox, uy = fy - oy, uz = fz - oz;
+  const float ex = (f.R[0] * ux + f.R[3] * uy + f.R[6] * uz) / f.Sinv;
+  const float ey = (f.R[1] * ux + f.R[4] * uy + f.R[7] * uz) / f.Sinv;
+  const float ez = (f.R[2] * ux + f.R[5] * uy + f.R[8] * uz) / f.Sinv;
+  const float wx = sx - ox, wy = sy - oy, wz = sz - oz;
+  const float qx = (f.R[0] * wx + f.R[3] * wy + f.R[6] * wz) / f.Sinv;
+  const float qy = (f.R[1] * wx + f.R[4] * wy + f.R[7] * wz) / f.Sinv;
+  const float qz = (f.R[2] * wx + f.R[5] * wy + f.R[8] * wz) / f.Sinv;
+  h.entry = v3(ex, ey, ez);
+  h.exit = v3(qx, qy, qz);
+  h.tb_minus = f.tb0 + (fy / f.Sinv);                               // :297-298: no ordering of the two
+  h.tb_plus = f.tb0 + (sy / f.Sinv);
+  h.tc_minus = pb_sqrt(ex * ex + ey * ey + ez * ez);
+  h.tc_plus = pb_sqrt(qx * qx + qy * qy + qz * qz);
+  return 2;
+}
+
+// Integral_721_ada (BeamRadiance.h:63-84): the Riemann sum in steps of 0.001 along the view ray, in double.
+// f.len of a cone record is |end - orig_start|, the reference's length_const.  The step count is bounded
+// (the reference's loop is not): a hit whose exit distance overflowed must not keep a wave running.
+PB_DI double integral_721_ada(const SegFrame& f, const CylHit& h, const Ray& r, float extinction, float scattering_c) {
+  const V3 l = r.l;
+  const float cos_f = f.bdir[0] * (-l.x) + f.bdir[1] * (-l.y) + f.bdir[2] * (-l.z);
+  const double ac = __builtin_fabs((double)cos_f);
+  const double width = (double)f.radius / (double)f.len;
+  const double ext = (double)extinction, sc = (double)scattering_c;
+  const double tcm = (double)h.tc_minus, tcp = (double)h.tc_plus, tbm = (double)h.tb_minus;
+  const double dt_c = 0.001;
+  double integrand = 0.0;
+  int guard = 0;
+  for (double tc = tcm; tc < tcp && guard < 1000000; tc = tc + dt_c, ++guard) {
+    const double tb = tbm - (ac * (tc - tcm));
+    const double current_r = width * tb;
+    const double constant = exp(-ext * tb);
+    const double transmitted = exp(-ext * tc) * constant * (sc / (current_r * current_r)) * dt_c;
+    integrand += transmitted;
+  }
+  return integrand;
+}
+
+// One (ray, segment) pair of BeamRadiance (BeamRadiance.h:486-543): a cone record goes through HitCone and
+// Integral_721_ada, any other through HitCylinder and Integral_73 (ONE_DIMENSIONAL; Integral_73Het's
+// arithmetic when a grid is given, :159-188) or Integral_721.
+PB_DI int eval_pair_generic(const SegFrame& f, const HetFrame& hf, V3 seg_start, V3 seg_end, const GridView& grid,
+                            bool one_dimensional, const Ray& r, float extinction_c, float scattering_c,
+                            double& integral_out) {
+  if (f.qflags & 32u) {
+    ConeFrame cf;
+    __builtin_memcpy(&cf, &hf, sizeof(cf));
+    CylHit h;
+    const int res = hit_cone_exact(f, cf, r, h);
+    if (res != 2) return res;
+    integral_out = integral_721_ada(f, h, r, extinction_c, scattering_c);
+    return 2;
+  }
+  if (one_dimensional) return eval_pair_73het(f, hf, seg_start, seg_end, grid, r, extinction_c, scattering_c, integral_out);
+  return eval_pair_721(f, r, extinction_c, integral_out);
+}
+
 // The same pair evaluation with the arithmetic the estimate is continuous in relaxed to what the
 // hardware does fastest; the radiance differs from the exact-order form above by the reference's own
 // float rounding noise (about 1e-5 relative per pixel), far inside the stated tolerance.

@@ -77,7 +77,21 @@ __device__ void gate_setup(const float lo[3], const float hi[3], float cand[3], 
   qflags = q;
 }
 
-__global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int n, int mode, float scattering_c,
+// Largest distance from a corner of the box to the segment a-b.
+__device__ float box_reach(const float lo[3], const float hi[3], V3 a, V3 b) {
+  const V3 ab = b - a;
+  const float ll = dot3(ab, ab);
+  float far = 0.0f;
+  for (int k = 0; k < 8; ++k) {
+    const V3 c = v3((k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]);
+    float t = ll > 0.0f ? dot3(c - a, ab) / ll : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    far = fmaxf(far, length3(c - (a + ab * t)));
+  }
+  return far;
+}
+
+__global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int n, int mode, int one_dimensional, float scattering_c,
                                         SegFrame* __restrict__ frames, float4* __restrict__ capA,
                                         float4* __restrict__ capB, HetFrame* __restrict__ het) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,17 +100,32 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
   V3 start = v3(s.start[0], s.start[1], s.start[2]);
   V3 end = v3(s.end[0], s.end[1], s.end[2]);
   V3 ostart = v3(s.orig_start[0], s.orig_start[1], s.orig_start[2]);
-  // HitCylinder, Intersections.h:313-328
-  V3 difference = end - start;
+  // HitCylinder, Intersections.h:313-328; HitCone (:151-175) builds the same frame about orig_start
+  const bool cone = (mode == PB_MODE_GENERIC) && (s.flags & 1u);
+  const V3 base = cone ? ostart : start;
+  V3 difference = end - base;
   float len = length3(difference);
   V3 w_unit = normalize3(v3(0.0f, len, 0.0f));
   float Sinv = 1 / len;
   V3 c_unit = difference * Sinv;
   M3 Rinv = find_rotation_matrix(c_unit, w_unit);
-  V3 Tinv = -(mul(Rinv, start) * Sinv);
+  V3 Tinv = -(mul(Rinv, base) * Sinv);
   float rs = s.radius * Sinv;
   // float + float - double, rounded to float once (Intersections.h:344-346)
   float c = (float)((double)(Tinv.x * Tinv.x + Tinv.z * Tinv.z) - (double)rs * (double)rs);
+  ConeFrame cf;
+  cf.c2 = 1.0; cf.s2 = 0.0; cf.pad[0] = cf.pad[1] = cf.pad[2] = cf.pad[3] = 0.0f;
+  float ymin = 0.0f;
+  if (cone) {
+    // :169-175, :196-200.  cosf/sinf of the host library are the correctly rounded values (to within a
+    // rounding boundary met about once in 1e8 arguments); the double routines rounded to float give the same.
+    const float tan_theta = rs / len;
+    const float ct = (float)cos((double)tan_theta), st = (float)sin((double)tan_theta);
+    cf.c2 = (double)ct * (double)ct;
+    cf.s2 = (double)st * (double)st;
+    c = (float)(cf.c2 * (double)(Tinv.x * Tinv.x + Tinv.z * Tinv.z) - (cf.s2 * (double)Tinv.y) * (double)Tinv.y);
+    ymin = ((mul(Rinv, start) * Sinv) + Tinv).y;
+  }
   M3 R = inverse3(Rinv);
   SegFrame f;
   for (int col = 0; col < 3; ++col)
@@ -108,7 +137,9 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
   V4 d4 = v4(start.x - ostart.x, start.y - ostart.y, start.z - ostart.z, 0.0f);
   f.tb0 = length4(d4);
   f.ox2 = 2 * Tinv.x; f.oz2 = 2 * Tinv.z;
-  f.bdir[0] = c_unit.x; f.bdir[1] = c_unit.y; f.bdir[2] = c_unit.z;
+  // beam_dir of the estimators is normalize(end - start) (BeamRadiance.h:64, :87) also where the frame is a cone's
+  const V3 bdir = cone ? normalize3(end - start) : c_unit;
+  f.bdir[0] = bdir.x; f.bdir[1] = bdir.y; f.bdir[2] = bdir.z;
   for (int k = 0; k < 3; ++k) { f.lo[k] = s.cull_lo[k]; f.hi[k] = s.cull_hi[k]; }
   gate_setup(f.lo, f.hi, f.cand, f.qflags);
   {
@@ -123,13 +154,14 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
       const float tol = 4e-6f * (1.0f + fmaxf(fabsf(mn), fabsf(mx)));
       contains = contains && (f.lo[k] <= mn + tol) && (f.hi[k] >= mx - tol);
     }
-    if (contains && len > 0.0f) f.qflags |= 16u;
+    if (contains && len > 0.0f && !cone) f.qflags |= 16u;
   }
+  if (cone) f.qflags |= 32u;
   // BeamRadiance.h:446-455 (721) / :389-397 (73het): energy * phase_f [* rad]
   double phase_f = 1 / (4 * PB_PI_REF);
   for (int k = 0; k < 3; ++k) {
     double w = (double)s.energy[k] * phase_f;
-    if (mode == PB_MODE_721) {
+    if (mode == PB_MODE_721 || (mode == PB_MODE_GENERIC && !cone && !one_dimensional)) {
       double rad = (double)scattering_c / (PB_PI_REF * ((double)s.radius * (double)s.radius));
       w = w * rad;
     }
@@ -137,15 +169,22 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
   }
   f.radius = s.radius;
   f.len = len;
-  f.pad = 0.0f;
+  f.ymin = ymin;
   frames[i] = f;
-  capA[i] = make_float4(start.x, start.y, start.z, s.radius);
+  // Culling radius.  A cylinder lies within `radius` of its axis.  A cone's quadric (and its second nappe,
+  // which HitCone does not exclude) can reach anywhere, but a contribution needs the ray to enter the
+  // segment's gate box (BeamRadiance.h:476-479): an adaptive-width segment is culled by a capsule around
+  // that box, in every mode, so that the bounding hierarchy does not depend on the estimator.
+  float reach = s.radius;
+  if (s.flags & 1u) reach = fmaxf(reach, box_reach(f.lo, f.hi, start, end));
+  capA[i] = make_float4(start.x, start.y, start.z, reach);
   capB[i] = make_float4(end.x, end.y, end.z, 0.0f);
   HetFrame h;
   h.os[0] = ostart.x; h.os[1] = ostart.y; h.os[2] = ostart.z;
   h.s_ext = s.s_ext; h.e_ext = s.e_ext; h.c_ext = s.c_ext;
   h.seg_id = s.seg_id; h.radius = s.radius;
-  het[i] = h;
+  if (cone) *reinterpret_cast<ConeFrame*>(&het[i]) = cf;
+  else het[i] = h;
 }
 
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_matrix16, TriPrep* d_out,
@@ -156,11 +195,11 @@ int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_ma
   return PB_OK;
 }
 
-int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, float scattering_c, SegFrame* d_frames,
+int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int one_dimensional, float scattering_c, SegFrame* d_frames,
                                float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s) {
   if (n <= 0) return PB_OK;
-  hipLaunchKernelGGL(prepare_segments_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_segs, n, mode, scattering_c,
-                     d_frames, d_capA, d_capB, d_het);
+  hipLaunchKernelGGL(prepare_segments_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_segs, n, mode, one_dimensional,
+                     scattering_c, d_frames, d_capA, d_capB, d_het);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }

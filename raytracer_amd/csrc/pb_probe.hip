@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void probe_box_kernel(const float* __restrict__
 __global__ __launch_bounds__(64) void probe_pair_kernel(const SegFrame* __restrict__ frames, const HetFrame* __restrict__ het,
                                                         const float4* __restrict__ capA, const float4* __restrict__ capB,
                                                         GridView grid, const float* __restrict__ dir, int n, int mode,
-                                                        int fast, float extinction_c, float scattering_c,
+                                                        int one_dimensional, int fast, float extinction_c, float scattering_c,
                                                         float* __restrict__ out12, double* __restrict__ integral,
                                                         int* __restrict__ status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,7 +82,12 @@ __global__ __launch_bounds__(64) void probe_pair_kernel(const SegFrame* __restri
   const Ray r = ray_from_dir(v4(dir[4 * i], dir[4 * i + 1], dir[4 * i + 2], dir[4 * i + 3]), 3.402823466e+38f);
   CylHit h;
   h.entry = v3(0, 0, 0); h.exit = v3(0, 0, 0); h.tb_minus = h.tb_plus = h.tc_minus = h.tc_plus = 0.0f;
-  const int res = hit_cylinder_exact(f, r, h);
+  int res;
+  if (f.qflags & 32u) {
+    ConeFrame cf;
+    __builtin_memcpy(&cf, &het[i], sizeof(cf));
+    res = hit_cone_exact(f, cf, r, h);
+  } else res = hit_cylinder_exact(f, r, h);
   float* o = out12 + (size_t)i * 12;
   for (int k = 0; k < 12; ++k) o[k] = 0.0f;
   o[0] = h.first_inte ? 1.0f : 0.0f;
@@ -93,7 +98,11 @@ __global__ __launch_bounds__(64) void probe_pair_kernel(const SegFrame* __restri
   double val = 0.0;
   int st;
   unsigned long long wrong = 0;
-  if (mode != PB_MODE_721) {
+  if (mode == PB_MODE_GENERIC) {
+    const float4 A = capA[i], B = capB[i];
+    st = eval_pair_generic(f, het[i], v3(A.x, A.y, A.z), v3(B.x, B.y, B.z), grid, one_dimensional != 0, r, extinction_c,
+                           scattering_c, val);
+  } else if (mode != PB_MODE_721) {
     const float4 A = capA[i], B = capB[i];
     st = eval_pair_73het(f, het[i], v3(A.x, A.y, A.z), v3(B.x, B.y, B.z), grid, r, extinction_c, scattering_c, val);
   } else if (fast) st = eval_pair_721_fast<false>(f, r, extinction_c, val, wrong);
@@ -160,7 +169,9 @@ extern "C" int pb_probe_hit_bounding_box(pb_ctx* ctx, const float* lo_xyz, const
 extern "C" int pb_probe_pairs(pb_ctx* ctx, const pb_segment* segs, const float* dir_xyzw, int n, int mode, int fast,
                               float* cyl_out12, double* integral, int32_t* status) {
   if (!ctx || !segs || !dir_xyzw || !cyl_out12 || !integral || !status || n < 0) { pb_set_error("pb_probe_pairs: bad argument"); return PB_ERR_ARG; }
-  if (mode != PB_MODE_721 && mode != PB_MODE_73HET && mode != PB_MODE_73) { pb_set_error("pb_probe_pairs: mode must be PB_MODE_721, PB_MODE_73 or PB_MODE_73HET"); return PB_ERR_ARG; }
+  if (mode != PB_MODE_721 && mode != PB_MODE_73HET && mode != PB_MODE_73 && mode != PB_MODE_GENERIC) {
+    pb_set_error("pb_probe_pairs: mode must be PB_MODE_721, PB_MODE_73, PB_MODE_73HET or PB_MODE_GENERIC"); return PB_ERR_ARG;
+  }
   if (mode == PB_MODE_73HET && !ctx->d_grid) { pb_set_error("pb_probe_pairs: PB_MODE_73HET needs pb_set_grid"); return PB_ERR_STATE; }
   if (n == 0) return PB_OK;
   PB_HIP(hipSetDevice(ctx->device));
@@ -176,12 +187,13 @@ extern "C" int pb_probe_pairs(pb_ctx* ctx, const pb_segment* segs, const float* 
   double* d_int = out.as<double>(); float* d_cyl = (float*)(d_int + nn); int* d_status = (int*)(d_cyl + 12 * nn);
   PB_HIP(hipMemcpyAsync(d_segs, segs, sizeof(pb_segment) * nn, hipMemcpyHostToDevice, s));
   PB_HIP(hipMemcpyAsync(d_dir, dir_xyzw, sizeof(float) * 4 * nn, hipMemcpyHostToDevice, s));
-  int rc = pb_launch_prepare_segments(d_segs, n, mode, ctx->ctl.scattering_c, d_frames, d_capA, d_capB, d_het, s);
+  int rc = pb_launch_prepare_segments(d_segs, n, mode, ctx->ctl.one_dimensional, ctx->ctl.scattering_c, d_frames, d_capA, d_capB, d_het, s);
   if (rc != PB_OK) return rc;
   GridView g;
-  g.z = (mode == PB_MODE_73HET) ? ctx->d_grid : nullptr; g.side = ctx->grid_side;
+  const bool generic_het = mode == PB_MODE_GENERIC && ctx->ctl.one_dimensional && ctx->ctl.heterogeneous && ctx->d_grid;
+  g.z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; g.side = ctx->grid_side;
   hipLaunchKernelGGL(probe_pair_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_frames, d_het, d_capA, d_capB, g, d_dir, n, mode,
-                     fast, ctx->ctl.absorption_c + ctx->ctl.scattering_c, ctx->ctl.scattering_c, d_cyl, d_int, d_status);
+                     ctx->ctl.one_dimensional, fast, ctx->ctl.absorption_c + ctx->ctl.scattering_c, ctx->ctl.scattering_c, d_cyl, d_int, d_status);
   PB_HIP(hipGetLastError());
   PB_HIP(hipMemcpyAsync(cyl_out12, d_cyl, sizeof(float) * 12 * nn, hipMemcpyDeviceToHost, s));
   PB_HIP(hipMemcpyAsync(integral, d_int, sizeof(double) * nn, hipMemcpyDeviceToHost, s));

@@ -234,12 +234,15 @@ PB_DI SegFrame fetch_frame(const SegFrame* frames, int sidx) {
 template <bool COUNT, bool PRECISE, int MODE>
 PB_DI int eval_pair(const RenderParams& p, int sidx, const SegFrame& f, const Ray& r, double& integral,
                     unsigned long long& c_wrong) {
-  if (MODE == PB_MODE_73HET) {
+  if (MODE == PB_MODE_73HET || MODE == PB_MODE_GENERIC) {
     const HetFrame hf = pb_uniform(p.het)[sidx];
     const PB_CONST_AS float* A = pb_uniform((const float*)p.capA) + 4 * (size_t)sidx;
     const PB_CONST_AS float* B = pb_uniform((const float*)p.capB) + 4 * (size_t)sidx;
     GridView grid;
     grid.z = p.grid_z; grid.side = p.grid_side;
+    if (MODE == PB_MODE_GENERIC)
+      return eval_pair_generic(f, hf, v3(A[0], A[1], A[2]), v3(B[0], B[1], B[2]), grid, p.one_dimensional != 0, r,
+                               p.extinction_c, p.scattering_c, integral);
     return eval_pair_73het(f, hf, v3(A[0], A[1], A[2]), v3(B[0], B[1], B[2]), grid, r, p.extinction_c, p.scattering_c,
                            integral);
   }
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
     r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
     r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
     r.maxd = rr[6 * 64 + lane];
-    r.d1 = (MODE == PB_MODE_73HET) ? v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]) : r.dn;
+    r.d1 = (MODE != PB_MODE_721) ? v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]) : r.dn;
     r.active = r.maxd >= 0.0f;
     double acc[3] = {0.0, 0.0, 0.0};
     for (int k = 0; k < n; ++k) {
@@ -721,7 +724,7 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
     r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
     r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
     r.maxd = rr[6 * 64 + lane];
-    r.d1 = (MODE == PB_MODE_73HET) ? v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]) : r.dn;
+    r.d1 = (MODE != PB_MODE_721) ? v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]) : r.dn;
     r.active = r.maxd >= 0.0f;
     unsigned long long ai[3] = {0ull, 0ull, 0ull};
     uint32_t nc = 0;
@@ -759,8 +762,9 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
         double integral = 0.0;
         const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong);
         if (res == 2) {
-          if (MODE == PB_MODE_73HET) {
-            // 1/sin(theta) is unbounded for a beam seen end-on: saturate far above the display range
+          if (MODE != PB_MODE_721) {
+            // 1/sin(theta) is unbounded for a beam seen end-on, 1/r^2 at a cone's apex: saturate far above
+            // the display range
             integral = fmin(integral, PB_FIX_LIMIT / fmax(f.W[0], fmax(f.W[1], f.W[2])));
           }
           ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
@@ -846,7 +850,11 @@ int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream
   int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;   // one wave per chunk
   if (waves > p.chunk_capacity) waves = p.chunk_capacity;
   if (waves < 1) waves = 1;
-  if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
+  if (mode == PB_MODE_GENERIC) {
+    if (count) hipLaunchKernelGGL((eval_kernel<true, true, PB_MODE_GENERIC>), dim3(waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((eval_kernel<false, true, PB_MODE_GENERIC>), dim3(waves), dim3(64), 0, s, p);
+  }
+  else if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
     if (count) hipLaunchKernelGGL((eval_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
     else hipLaunchKernelGGL((eval_kernel<false, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
   }
@@ -906,7 +914,11 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;
   if (waves > p.item_capacity) waves = p.item_capacity;
   if (waves < 1) waves = 1;
-  if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
+  if (mode == PB_MODE_GENERIC) {
+    if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_GENERIC>), dim3(waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_GENERIC>), dim3(waves), dim3(64), 0, s, p);
+  }
+  else if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
     if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
     else hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
   }

@@ -300,9 +300,9 @@ void DrawStandard(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>)
 
 void Draw(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, std::vector<PhotonSeg>&) {
   pb_ctx* ctx = context();
-  const int mode = control.one_dimensional ? (control.heterogeneous ? PB_MODE_73HET : PB_MODE_73) : PB_MODE_721;
+  // BeamRadiance's per-segment dispatch (BeamRadiance.h:486-543): cones if ADAPTIVE, else by ONE_DIMENSIONAL
   std::vector<float> rgb((size_t)scr->width * scr->height * 3);
-  check(pb_render(ctx, 0, 0, scr->width, scr->height, mode, /*screen bins*/ 2, rgb.data()), "pb_render");
+  check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_DEFAULT, /*screen bins*/ 2, rgb.data()), "pb_render");
   check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
 }
 

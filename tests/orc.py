@@ -16,6 +16,7 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref.so")
 MODE_721 = 721
 MODE_73HET = 73
 MODE_73 = 730
+MODE_GENERIC = 471
 
 
 class Control(C.Structure):
@@ -104,6 +105,7 @@ def lib():
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_integral_721.restype = C.c_double
         L.orc_integral_73het.restype = C.c_double
+        L.orc_integral_721_ada.restype = C.c_double
         for name in ("orc_cast_photon_beams", "orc_beam_counts", "orc_get_beams", "orc_bound_photon_beams",
                      "orc_build_tree", "orc_tree_stats", "orc_root_box", "orc_export_segments", "orc_set_grid",
                      "orc_make_grid", "orc_render_tree"):
@@ -173,6 +175,21 @@ def hit_cylinder(start, dir, s0, s1, so, radius, use_ref=False):
     f(_fp(_f32(start, 4)), _fp(_f32(dir, 4)), _fp(_f32(s0, 4)), _fp(_f32(s1, 4)), _fp(_f32(so, 4)),
       C.c_float(radius), _fp(out))
     return out
+
+
+def hit_cone(start, dir, s0, s1, so, radius, use_ref=False):
+    L = ref() if use_ref else lib()
+    f = getattr(L, ("ref_" if use_ref else "orc_") + "hit_cone")
+    out = np.zeros(12, np.float32)
+    f(_fp(_f32(start, 4)), _fp(_f32(dir, 4)), _fp(_f32(s0, 4)), _fp(_f32(s1, 4)), _fp(_f32(so, 4)),
+      C.c_float(radius), _fp(out))
+    return out
+
+
+def integral_721_ada(s0, s1, so, radius, tb_minus, tc_minus, tc_plus, extinction, scattering, dir):
+    return lib().orc_integral_721_ada(_fp(_f32(s0, 4)), _fp(_f32(s1, 4)), _fp(_f32(so, 4)), C.c_float(radius),
+                                      C.c_float(tb_minus), C.c_float(tc_minus), C.c_float(tc_plus),
+                                      C.c_float(extinction), C.c_float(scattering), _fp(_f32(dir, 4)))
 
 
 def find_rotation_matrix(c, w, use_ref=False):

@@ -253,3 +253,33 @@ def test_one_dimensional_homogeneous_estimator(pb):
         err = np.abs(img - ref)
         assert (err <= 1e-6 * np.maximum(1.0, np.abs(ref))).all(), (name, err.max())
     assert not np.allclose(std, frames["bins"], rtol=0.05)     # a different estimator, not the 2D one
+
+
+def test_adaptive_cones_generic_estimator(pb):
+    """ADAPTIVE: first-cast beams widen into cones, BeamRadiance (BeamRadiance.h:471-555) sends them through
+    HitCone + Integral_721_ada and scattered beams through HitCylinder + Integral_721.  The Riemann sum is in
+    double on both sides; 1/r^2 near a cone's apex makes single pixels huge, so the comparison is on the
+    displayed range (PutPixelSDL clamps at 1) and, relative, below the fixed-point saturation."""
+    kw = dict(photon_number=300, bounces=1, screen_width=96, screen_height=96, adaptive=1)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        ctx.build_tree()
+        frames = {c: ctx.draw(mode=pb.MODE_DEFAULT, cull=c).astype(np.float64) for c in ("scan", "lbvh", "bins")}
+        cyl = ctx.draw(mode=pb.MODE_721, cull="bins")
+    assert (segs["flags"] & 1).sum() > 200 and (segs["flags"] & 1).sum() < len(segs)
+    tri, _ = orc.load_test_model()
+    ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
+                                   segs, lo, hi, 0, 0, 96, 96, mode=orc.MODE_GENERIC)
+    assert cnt["valid_hits"] > 20000 and np.isfinite(ref).all() and (ref > 0).mean() > 0.3
+    for name, img in frames.items():
+        small = ref < 1000.0
+        err = np.abs(img - ref)
+        # the scattered beams' Integral_721 runs in float: device and host expf differ in the last bit
+        assert (err[small] <= 2e-5 + 1e-4 * np.abs(ref[small])).all(), (name, err[small].max())
+        assert (err[small] <= 1e-6 * np.maximum(1.0, np.abs(ref[small]))).mean() > 0.98, name
+        a, b = pb.quantise_argb(img), pb.quantise_argb(ref)
+        assert (a != b).mean() < 1e-3, name
+    assert not np.allclose(cyl, frames["bins"], rtol=0.05)

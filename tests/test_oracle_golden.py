@@ -77,6 +77,37 @@ def test_hit_cylinder_bit_exact(gold):
     assert_bit_equal(out, ref, "HitCylinder outputs")
 
 
+def test_hit_cone_bit_exact(gold):
+    """HitCone (Intersections.h:145-305) on adaptive-width beams of configuration 1, whole cones and frusta."""
+    n = len(gold["co_out"])
+    out = np.stack([orc.hit_cone(gold["co_start"][i], gold["co_dir"][i], gold["co_s0"][i], gold["co_s1"][i],
+                                 gold["co_so"][i], float(gold["co_radius"][i])) for i in range(n)])
+    ref = gold["co_out"]
+    assert (ref[:, 0] == 0).sum() > 500 and (ref[:, 1] == 1).sum() > 1000
+    assert ((ref[:, 0] == 1) & (ref[:, 1] == 0)).sum() >= 1
+    assert_bit_equal(out, ref, "HitCone outputs")
+
+
+def test_integral_721_ada_is_the_riemann_sum():
+    """Integral_721_ada (BeamRadiance.h:63-84) is restated only (its header needs SDL): check the sum against
+    an independent numpy evaluation of the same formula."""
+    s0 = np.array([0.1, -0.9, 2.2, 1], np.float32); s1 = np.array([0.3, 0.8, 2.9, 1], np.float32)
+    d = np.array([0.05, 0.1, 1, 1], np.float32); d /= np.float32(np.sqrt((d * d).sum()))
+    tb, tc0, tc1, ext, sca, rad = 0.9, 2.4, 2.4731, 0.04, 0.005, 0.045
+    got = orc.integral_721_ada(s0, s1, s0, rad, tb, tc0, tc1, ext, sca, d)
+    bd = (s1[:3] - s0[:3]).astype(np.float64); bd /= np.linalg.norm(bd)
+    cd = d[:3].astype(np.float64); cd /= np.linalg.norm(cd)
+    cos = abs(float(np.float32(-(bd * cd).sum())))
+    L = float(np.float32(np.linalg.norm((s0 - s1).astype(np.float64))))
+    tc = np.float64(np.float32(tc0)) + 0.001 * np.arange(int(np.ceil((np.float32(tc1) - np.float32(tc0)) / 0.001)) + 2)
+    tc = tc[tc < np.float64(np.float32(tc1))]
+    tbs = np.float64(np.float32(tb)) - cos * (tc - np.float64(np.float32(tc0)))
+    r = (np.float64(np.float32(rad)) / L) * tbs
+    e = np.float64(np.float32(ext))
+    want = (np.exp(-e * tc) * np.exp(-e * tbs) * (np.float64(np.float32(sca)) / r ** 2) * 0.001).sum()
+    assert len(tc) in (73, 74) and abs(got - want) <= 1e-6 * want
+
+
 def test_find_rotation_matrix_bit_exact(gold):
     n = len(gold["rot_c"])
     m = np.stack([orc.find_rotation_matrix(gold["rot_c"][i], gold["rot_w"][i]) for i in range(n)])
