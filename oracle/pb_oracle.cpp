@@ -1102,9 +1102,26 @@ static inline void leaf_segment(const PhotonSeg& seg, const dvec3& energy, const
   }
 }
 
-// Per-pixel setup of DrawStandard/DrawHet (skeleton.cpp:342-350).
+// The draw SHORT_VIEW makes per camera ray (skeleton.cpp:443).  kind 0: the reference's generator, drawn for a
+// whole frame in the reference's loop order (x outer, y inner, then the sub-samples) and looked up; kind 1:
+// the device's draw, philox keyed by the sub-pixel.
+struct ViewDraws {
+  int kind = 1;
+  uint32_t seed = 42;
+  int sub_h = 0;                       // SCREEN_HEIGHT * SSAA
+  std::vector<double> table;           // kind 0: [sub-pixel x * sub_h + sub-pixel y], NaN where no draw was made
+  double draw(int px, int py) const {
+    if (kind == 0) return table[(size_t)px * sub_h + py];
+    uint32_t c[4] = {(uint32_t)px, (uint32_t)py, 0u, 0u};
+    philox4x32_10(c, seed, 0x56494557u);
+    uint64_t hi = c[0] >> 5, lo = c[1] >> 6;
+    return (double)((hi << 26) | lo) * (1.0 / 9007199254740992.0);
+  }
+};
+
+// Per-pixel setup of DrawStandard/DrawHet (skeleton.cpp:342-350) and Draw (:428-449).
 static inline bool camera_ray(const Control& ctl, const std::vector<Triangle>& tris, const mat4& matrix,
-                              int px, int py, RayCtx& r) {
+                              int px, int py, RayCtx& r, const ViewDraws* view = nullptr) {
   const pb_control& C = ctl.c;
   float x_dir = px - ((C.screen_width * C.ssaa) / (float)2);
   float y_dir = py - ((C.screen_height * C.ssaa) / (float)2);
@@ -1113,6 +1130,14 @@ static inline bool camera_ray(const Control& ctl, const std::vector<Triangle>& t
   r.dir = direction;
   Intersection c_i;
   if (!ClosestIntersection(r.start, direction, c_i, matrix, tris)) return false;
+  if (C.short_view && view) {                            // skeleton.cpp:440-449
+    float max_distance = length(c_i.position - r.start);
+    float t_a = (float)(-(std::log(1 - view->draw(px, py)) / ctl.extinction_c()));
+    if (t_a > 0) {
+      max_distance = std::fmin(t_a, max_distance);
+      c_i.position = r.start + (direction * max_distance);
+    }
+  }
   r.max_distance = length(c_i.position - r.start);      // BeamRadiance.h:426
   return true;
 }
@@ -1580,6 +1605,24 @@ int orc_render_tree(orc_ctx* c, int x0, int y0, int w, int h, int mode, double* 
   Medium med{o.extinction_c(), o.scattering_c(), &o.GRID, o.ctl.c.one_dimensional != 0};
   orc_counters total{};
   (void)threads;
+  ViewDraws view;
+  view.kind = o.rng.kind; view.seed = o.ctl.c.seed; view.sub_h = o.ctl.c.screen_height * ssaa;
+  if (o.ctl.c.short_view && view.kind == 0) {
+    // the generator continues where the photon pass and BuildTree left it; one draw per camera ray that
+    // hits the scene, in Draw's loop order (skeleton.cpp:421-443)
+    std::mt19937 generator = o.rng.generator;
+    std::uniform_real_distribution<double> uniform(0.0, 1.0);
+    const int sub_w = o.ctl.c.screen_width * ssaa;
+    view.table.assign((size_t)sub_w * view.sub_h, std::nan(""));
+    for (int x = 0; x < sub_w; x += ssaa)
+      for (int y = 0; y < view.sub_h; y += ssaa)
+        for (int i = 0; i < ssaa; ++i)
+          for (int j = 0; j < ssaa; ++j) {
+            RayCtx r;
+            if (camera_ray(o.ctl, o.triangles, o.matrix, x + i, y + j, r))
+              view.table[(size_t)(x + i) * view.sub_h + (y + j)] = uniform(generator);
+          }
+  }
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
   {
     orc_counters cnt{};
@@ -1591,7 +1634,7 @@ int orc_render_tree(orc_ctx* c, int x0, int y0, int w, int h, int mode, double* 
           for (int j = 0; j < ssaa; ++j) {
             RayCtx r;
             cnt.rays++;
-            if (camera_ray(o.ctl, o.triangles, o.matrix, (x0 + xx) * ssaa + i, (y0 + yy) * ssaa + j, r)) {
+            if (camera_ray(o.ctl, o.triangles, o.matrix, (x0 + xx) * ssaa + i, (y0 + yy) * ssaa + j, r, &view)) {
               cnt.rays_hit_scene++;
               traverse(o, 0, r, mode, med, current, cnt);
             }
@@ -1643,6 +1686,8 @@ int orc_render_segments_strided(const pb_control* control, const float* tri_xyz,
   const int ssaa = ctl.c.ssaa;
   orc_counters total{};
   (void)threads;
+  ViewDraws view;                     // no generator state here: the device's per-ray draws
+  view.kind = 1; view.seed = ctl.c.seed; view.sub_h = ctl.c.screen_height * ssaa;
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
   {
     orc_counters cnt{};
@@ -1654,7 +1699,7 @@ int orc_render_segments_strided(const pb_control* control, const float* tri_xyz,
           for (int j = 0; j < ssaa; ++j) {
             RayCtx r;
             cnt.rays++;
-            if (!camera_ray(ctl, tris, M, (x0 + xx * step_x) * ssaa + i, (y0 + yy * step_y) * ssaa + j, r)) continue;
+            if (!camera_ray(ctl, tris, M, (x0 + xx * step_x) * ssaa + i, (y0 + yy * step_y) * ssaa + j, r, &view)) continue;
             cnt.rays_hit_scene++;
             cnt.node_visits++;
             if (!box_gate(root, r)) continue;

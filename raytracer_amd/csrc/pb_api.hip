@@ -233,6 +233,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   const bool generic_het = mode == PB_MODE_GENERIC && ctx->ctl.one_dimensional && ctx->ctl.heterogeneous;
   p.het = ctx->d_het; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side;
   p.one_dimensional = ctx->ctl.one_dimensional;
+  p.short_view = ctx->ctl.short_view; p.view_seed = ctx->ctl.seed;
   if (generic_het && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_GENERIC with one_dimensional and heterogeneous set needs pb_set_grid"); return PB_ERR_STATE; }
   if (mode == PB_MODE_73HET && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_73HET needs pb_set_grid"); return PB_ERR_STATE; }
   p.x0 = x0; p.y0 = y0; p.out_w = out_w; p.out_h = out_h; p.strip_stride = strip_stride;

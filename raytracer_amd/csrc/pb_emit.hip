@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "pb_internal.h"
+#include "pb_philox.h"
 #include "pb_geom.h"
 #include "pb_grid.h"
 #include "pb_scan.h"
@@ -22,27 +23,10 @@ namespace {
 constexpr int EMIT_THREADS = 64;
 constexpr int MAX_STACK = 8;   // nesting of in-medium scattering events kept per photon
 
-PB_DI void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-
 struct Rng {
   uint32_t photon, draw, k0, k1;
   PB_DI double canonical() {
-    uint32_t c[4] = {photon, draw++, 0u, 0u};
-    philox4x32_10(c, k0, k1);
-    const uint64_t hi = c[0] >> 5, lo = c[1] >> 6;
-    return (double)((hi << 26) | lo) * (1.0 / 9007199254740992.0);
+    return philox_canonical(photon, draw++, k0, k1);
   }
   PB_DI double range(double a, double b) { return canonical() * (b - a) + a; }
   PB_DI double uniform() { return range(0.0, 1.0); }                           // CastPhotons.h:87

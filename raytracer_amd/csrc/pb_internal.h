@@ -104,6 +104,8 @@ struct RenderParams {
   float scattering_c;      // Control.h:47
   const HetFrame* het;     // per segment: Integral_73/73Het inputs, or a ConeFrame where qflags bit 5 is set
   int one_dimensional;     // ONE_DIMENSIONAL, read by PB_MODE_GENERIC
+  int short_view;          // SHORT_VIEW
+  uint32_t view_seed;      // Control seed: key of the camera rays' draws
   const float* grid_z;     // sigma_t field (side*side) or nullptr
   int grid_side;
   // geometry of this launch: tile (tx, k) covers pixels x = x0 + 8*tx + lx,

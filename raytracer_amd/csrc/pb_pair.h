@@ -7,6 +7,7 @@
 #include "pb_internal.h"
 #include "pb_geom.h"
 #include "pb_grid.h"
+#include "pb_philox.h"
 
 struct Ray {
   V3 l;        // normalize(vec3(dir))              Intersections.h:313, BeamRadiance.h:88
@@ -87,6 +88,17 @@ PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
   float dist; int idx;
   r.active = closest_intersection(p.tris, p.n_tri, start, dir, pos, dist, idx, p.tri_box);
   r.maxd = r.active ? length4(pos - start) : -1.0f;
+  if (p.short_view && r.active) {
+    // SHORT_VIEW (skeleton.cpp:442-449): the view ray ends at a free-flight distance drawn for it; the draw
+    // is keyed by the sub-pixel, not by the order in which pixels are visited
+    const double u = philox_canonical((uint32_t)sx, (uint32_t)sy, p.view_seed, PB_VIEW_KEY);
+    const float t_a = (float)(-(log(1 - u) / (double)p.extinction_c));
+    if (t_a > 0) {
+      const float md = fminf(t_a, r.maxd);
+      pos = start + (dir * md);
+      r.maxd = length4(pos - start);          // BeamRadiance.h:474 on the moved limit
+    }
+  }
   r.l = normalize3(xyz(dir));
   r.dn = xyz(normalize4(dir));
   r.d1 = xyz(dir);

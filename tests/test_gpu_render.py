@@ -283,3 +283,29 @@ def test_adaptive_cones_generic_estimator(pb):
         a, b = pb.quantise_argb(img), pb.quantise_argb(ref)
         assert (a != b).mean() < 1e-3, name
     assert not np.allclose(cyl, frames["bins"], rtol=0.05)
+
+
+def test_short_view_rays(pb):
+    """SHORT_VIEW (skeleton.cpp:442-449): each camera ray ends at a free-flight distance drawn for it, which
+    moves the limit of every gate.  The device keys the draw by the sub-pixel; the oracle makes the same draws.
+    Strong extinction so that most rays end in the medium."""
+    kw = dict(photon_number=600, bounces=1, screen_width=128, screen_height=96, short_view=1, ssaa=2,
+              absorption_c=0.3, scattering_c=0.1)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        ctx.build_tree()
+        ctx.set_precise(True)
+        frames = {c: ctx.draw(mode=pb.MODE_721, cull=c).astype(np.float64) for c in ("scan", "lbvh", "bins")}
+        ctx.set_precise(False)
+        fast = ctx.draw(mode=pb.MODE_721, cull="bins").astype(np.float64)
+    tri, _ = orc.load_test_model()
+    args = (orc.tri_xyz(tri), orc.transformation_matrix(), segs, lo, hi, 0, 0, 128, 96)
+    ref, cnt = orc.render_segments(orc.control_defaults(**kw), *args, mode=orc.MODE_721)
+    full, cnt_full = orc.render_segments(orc.control_defaults(**dict(kw, short_view=0)), *args, mode=orc.MODE_721)
+    assert cnt["valid_hits"] > 1000 and cnt["valid_hits"] < 0.8 * cnt_full["valid_hits"]
+    for name, img in frames.items():
+        assert np.abs(img - ref).max() <= 2e-5 + 1e-4 * ref.max(), name
+    assert np.abs(fast - ref).max() <= 1e-4 * max(1.0, ref.max())

@@ -29,3 +29,21 @@ def test_counter_rng_emission_is_statistically_like_mt19937():
     first_c = bc[(bc["order"] == 0) & (bc["photon"] == 57)]
     first_b = bb[(bb["order"] == 0) & (bb["photon"] == 57)]
     assert first_c.tobytes() == first_b.tobytes()
+
+
+def test_short_view_draws_follow_the_reference_generator():
+    """SHORT_VIEW with the reference's generator (skeleton.cpp:442-449): one draw per camera ray that hits the
+    scene, in Draw's loop order, continuing after the photon pass and BuildTree.  Parity unpinned (Draw needs
+    SDL to build): checked for determinism, for rectangle independence and against the draws made by hand."""
+    kw = dict(photon_number=200, screen_width=48, screen_height=40, short_view=1, absorption_c=0.3, scattering_c=0.1)
+    o = orc.Oracle(orc.control_defaults(**kw))
+    o.cast_photon_beams(); o.bound_photon_beams(); o.build_tree()
+    a, ca = o.render_tree(0, 0, 48, 40)
+    b, _ = o.render_tree(0, 0, 48, 40)
+    part, _ = o.render_tree(8, 16, 16, 8)
+    assert np.array_equal(a, b) and np.array_equal(part, a[16:24, 8:24])
+    o2 = orc.Oracle(orc.control_defaults(**dict(kw, short_view=0)))
+    o2.cast_photon_beams(); o2.bound_photon_beams(); o2.build_tree()
+    full, cf = o2.render_tree(0, 0, 48, 40)
+    assert 0 < ca["valid_hits"] < 0.9 * cf["valid_hits"]
+    assert (a <= full + 1e-12).all() and (a < full - 1e-9).any()     # a shorter view ray can only lose segments
