@@ -2,8 +2,10 @@
 // against raytracer_amd/host/photon_beams_host.h: the same calls in the same order, one frame,
 // screenshot.bmp written headless.
 //   ./skeleton_headless [photons] [bounces] [width] [out.bmp] [het]
+//   ./skeleton_headless analysis      RUN_ANALYSIS (skeleton.cpp:82-84): NSD.csv and rRMSE.csv, no frame
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <vector>
 
@@ -12,6 +14,10 @@
 using namespace pbhost;
 
 int main(int argc, char** argv) {
+  if (argc > 1 && std::strcmp(argv[1], "analysis") == 0) {
+    try { RunAnalysis(); Shutdown(); } catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
+    return 0;
+  }
   if (argc > 1) control.photon_number = std::atoi(argv[1]);
   if (argc > 2) control.bounces = std::atoi(argv[2]);
   if (argc > 3) control.screen_width = control.screen_height = std::atoi(argv[3]);

@@ -261,6 +261,16 @@ int pb_probe_hit_bounding_box(pb_ctx* ctx, const float* lo_xyz, const float* hi_
 int pb_probe_pairs(pb_ctx* ctx, const pb_segment* segs, const float* dir_xyzw, int n, int mode, int fast,
                    float* cyl_out12, double* integral, int32_t* status);
 
+/* RunAnalysis (Analysis.h:81-122): the estimator variance study for the reference's fixed geometry
+ * (SetUpAnalysis, :455-475), one GPU lane per kernel width.  table 0 = NSD.csv: normalised standard
+ * deviation of BsBs2D1, BsBs1D, BsBl2D2, PBl3D, BsBl1D, BlBs1D, BlP3D, PBs2D (:94-101); table 1 =
+ * rRMSE.csv: rBsBs2D1, rBsBl1D, rBlP3D (:111-117).  extinction = analysis_extinction (:15; the
+ * reference's is EXT_ANALYSIS = 0.04f widened to double).  Row r: first_col[r] = kernel_width / mfp,
+ * values[r*cols + k], present[r*cols + k] = 0 where the reference writes an empty cell.  *n_rows is set
+ * even when capacity_rows is too small (PB_ERR_CAPACITY). */
+int pb_run_analysis(pb_ctx* ctx, double extinction, int table, double* first_col, double* values,
+                    uint8_t* present, int capacity_rows, int* n_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,6 +135,21 @@ def main():
     out["co_out"] = res
     print("cone true", int(res[:, 0].sum()), "cone valid", int(res[:, 1].sum()))
 
+    # RunAnalysis: the reference's own function writes NSD.csv (identical to the file it has committed, kept as
+    # tests/golden/reference_NSD.csv) and rRMSE.csv (kept as tests/golden/ref_rRMSE.csv)
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            orc.ref().ref_run_analysis()
+        finally:
+            os.chdir(cwd)
+        gold = os.path.join(orc.ROOT, "tests", "golden")
+        assert open(os.path.join(tmp, "NSD.csv")).read() == open(os.path.join(gold, "reference_NSD.csv")).read()
+        shutil.copy(os.path.join(tmp, "rRMSE.csv"), os.path.join(gold, "ref_rRMSE.csv"))
+
     dst = os.path.join(orc.ROOT, "tests", "golden", "ref_primitives.npz")
     np.savez_compressed(dst, **out)
     cy = out["cy_out"]

@@ -44,6 +44,8 @@ void orc_hit_cone(const float start[4], const float dir[4], const float seg_star
 double orc_integral_721_ada(const float seg_start[4], const float seg_end[4], const float seg_orig_start[4],
                             float radius, float tb_minus, float tc_minus, float tc_plus, float extinction,
                             float scattering, const float dir[4]);
+/* RunAnalysis (Analysis.h:81-122): table 0 = NSD.csv (8 columns), 1 = rRMSE.csv (3 columns); returns the row count */
+int orc_run_analysis(double extinction, int table, double* first_col, double* values, uint8_t* present, int capacity);
 void orc_find_rotation_matrix(const float c_dir[3], const float w_dir[3], float m9[9]);
 double orc_integral_721(const float seg_start[4], const float seg_end[4], float tb_minus, float tc_minus,
                         float tc_plus, float extinction, const float dir[4]);

@@ -2,7 +2,7 @@
 // Builds only where /root/reference exists (see oracle/Makefile, target _ref);
 // it #includes the reference headers where they lie and contains no reference
 // code.  Only the SDL-free headers are used: Control.h, TestModelH.h,
-// Tessendorf.h and Intersections.h.  CastPhotons.h, BeamRadiance.h and
+// Tessendorf.h, Intersections.h and Analysis.h.  CastPhotons.h, BeamRadiance.h and
 // Heterogeneous.h include <SDL.h> (absent in this image) and are not built.
 #include <glm/glm.hpp>
 #include <cstring>
@@ -15,6 +15,7 @@
 #include "TestModelH.h"
 #include "Tessendorf.h"
 #include "Intersections.h"
+#include "Analysis.h"
 
 static vec4 v4(const float* p) { return vec4(p[0], p[1], p[2], p[3]); }
 
@@ -106,6 +107,9 @@ int ref_create_surface(int triangle_number, float height, double time, float* pt
     for (int c = 0; c < 4; ++c) pts[i * 4 + c] = GRID.geometric_points[i][c];
   return (int)GRID.geometric_points.size();
 }
+
+// RunAnalysis (Analysis.h:81-122) writes NSD.csv and rRMSE.csv into the current directory.
+void ref_run_analysis(void) { RunAnalysis(); }
 
 void ref_control(float* out /*12*/) {
   for (int c = 0; c < 4; ++c) out[c] = light_position[c];

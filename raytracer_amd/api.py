@@ -245,6 +245,18 @@ class Context:
                "pb_extinction3d")
         return (mean, cnt, samp) if max_samples else (mean, cnt)
 
+    def run_analysis(self, table, extinction=float(np.float32(0.04))):
+        """RunAnalysis (Analysis.h:81-122): (kernel_width / mfp, values, present) of NSD.csv (table 0, 8
+        estimators) or rRMSE.csv (table 1, 3 estimators)."""
+        cols = 8 if table == 0 else 3
+        n = C.c_int(0)
+        cap = 4096
+        fc = np.zeros(cap); v = np.zeros((cap, cols)); p = np.zeros((cap, cols), np.uint8)
+        _check(self.L.pb_run_analysis(self.h, C.c_double(extinction), C.c_int(table), fc.ctypes.data_as(C.c_void_p),
+                                      v.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), C.c_int(cap),
+                                      C.byref(n)), "pb_run_analysis")
+        return fc[:n.value], v[:n.value], p[:n.value]
+
     # ---- known-answer probes: one GPU lane per query through the kernels' own device functions ----
     def probe_closest_intersection(self, start_xyzw, dir_xyzw):
         a = np.ascontiguousarray(start_xyzw, np.float32).reshape(-1, 4)

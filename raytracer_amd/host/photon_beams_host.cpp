@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <stdexcept>
 #include <string>
 
@@ -304,6 +305,33 @@ void Draw(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, std::ve
   std::vector<float> rgb((size_t)scr->width * scr->height * 3);
   check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_DEFAULT, /*screen bins*/ 2, rgb.data()), "pb_render");
   check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
+}
+
+void RunAnalysis() {
+  pb_ctx* ctx = context();
+  const double analysis_extinction = 0.04f;
+  const char* names[2] = {"NSD.csv", "rRMSE.csv"};
+  for (int table = 0; table < 2; ++table) {
+    const int cols = table == 0 ? 8 : 3;
+    int rows = 0;
+    std::vector<double> first(1), values(cols);
+    std::vector<uint8_t> present(cols);
+    int rc = pb_run_analysis(ctx, analysis_extinction, table, first.data(), values.data(), present.data(), 0, &rows);
+    if (rc != PB_OK && rc != PB_ERR_CAPACITY) check(rc, "pb_run_analysis");
+    first.assign((size_t)rows + 1, 0.0); values.assign((size_t)rows * cols + 1, 0.0); present.assign((size_t)rows * cols + 1, 0);
+    check(pb_run_analysis(ctx, analysis_extinction, table, first.data(), values.data(), present.data(), rows, &rows), "pb_run_analysis");
+    std::ofstream file;
+    file.open(names[table]);
+    for (int r = 0; r < rows; ++r) {
+      file << first[(size_t)r];                              // Analysis.h:93, :110
+      for (int k = 0; k < cols; ++k) {
+        file << ",";
+        if (present[(size_t)r * cols + k]) file << std::to_string(values[(size_t)r * cols + k]);
+      }
+      file << "\n";
+    }
+    file.close();
+  }
 }
 
 void DrawHet(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, NodeGen*) {

@@ -94,13 +94,17 @@ void KillSDL(screen* s);                                                        
 // uses its global `root`.
 void DrawStandard(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scatt);
 
-// skeleton.cpp:414-473 without ADAPTIVE and SHORT_VIEW: the estimator follows control.one_dimensional and
-// control.heterogeneous as BeamRadiance does (BeamRadiance.h:508-541).
+// skeleton.cpp:414-473: BeamRadiance's per-segment dispatch (BeamRadiance.h:486-543) — cones for adaptive-width
+// segments, else the estimator control.one_dimensional and control.heterogeneous select; control.short_view.
 void Draw(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scattered,
           std::vector<PhotonSeg>& items);
 // One frame of skeleton.cpp:367-412 (BVHBeamRadianceHet with Integral_73Het); the NodeGen argument is
 // unused there as well.
 void DrawHet(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<PhotonBeam> beams_scattered, NodeGen*);
+
+// Analysis.h:81-122: writes NSD.csv and rRMSE.csv into the current directory, in the reference's format
+// (analysis_extinction = EXT_ANALYSIS = 0.04f widened, Control.h:21, Analysis.h:15).
+void RunAnalysis();
 
 // Counters and device times of the last calls (pb_counters).
 pb_stats Stats();

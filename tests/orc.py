@@ -192,6 +192,25 @@ def integral_721_ada(s0, s1, so, radius, tb_minus, tc_minus, tc_plus, extinction
                                       C.c_float(extinction), C.c_float(scattering), _fp(_f32(dir, 4)))
 
 
+def run_analysis(table, extinction=float(np.float32(0.04))):
+    """RunAnalysis (Analysis.h:81-122) restated: (first column, values, present) of NSD.csv (table 0) or
+    rRMSE.csv (table 1).  EXT_ANALYSIS is the float 0.04f widened (Control.h:21, Analysis.h:15)."""
+    cols = 8 if table == 0 else 3
+    L = lib()
+    L.orc_run_analysis.argtypes = [C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    cap = 4096
+    fc = np.zeros(cap); v = np.zeros((cap, cols)); p = np.zeros((cap, cols), np.uint8)
+    n = L.orc_run_analysis(extinction, table, fc.ctypes.data, v.ctypes.data, p.ctypes.data, cap)
+    return fc[:n], v[:n], p[:n]
+
+
+def analysis_csv(first_col, values, present):
+    """The text RunAnalysis writes: `<<` of a double (%g) then `"," << to_string(x)` (%f) per cell, empty
+    where the estimator's kernel misses (Analysis.h:93-102)."""
+    return "".join("%g" % first_col[r] + "".join("," + ("%f" % values[r, k] if present[r, k] else "")
+                                                 for k in range(values.shape[1])) + "\n" for r in range(len(first_col)))
+
+
 def find_rotation_matrix(c, w, use_ref=False):
     L = ref() if use_ref else lib()
     f = getattr(L, ("ref_" if use_ref else "orc_") + "find_rotation_matrix")

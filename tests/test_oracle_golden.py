@@ -201,3 +201,13 @@ def test_flat_estimate_equals_tree_traversal(cfg1, cfg1_frame):
                                     0, y0, 512, h)
     assert np.array_equal(flat, cfg1_frame[0][y0:y0 + h])
     assert cnt["valid_hits"] > 100000
+
+
+def test_run_analysis_reproduces_reference_csv(golden_dir):
+    """RunAnalysis (Analysis.h:81-122): NSD.csv as the reference has it committed, rRMSE.csv as the reference's
+    own function writes it here (oracle/gen_golden.py) — text for text."""
+    nsd = orc.analysis_csv(*orc.run_analysis(0))
+    rrmse = orc.analysis_csv(*orc.run_analysis(1))
+    assert nsd == open(os.path.join(golden_dir, "reference_NSD.csv")).read()
+    assert rrmse == open(os.path.join(golden_dir, "ref_rRMSE.csv")).read()
+    assert nsd.count("\n") == 250 and rrmse.count("\n") == 317
