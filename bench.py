@@ -80,6 +80,39 @@ def measured_traffic(workload, cull):
         return None
 
 
+def pipelined_throughput(pb, torch, ctl, dev, segs, root, het, grid, mode, cull, W, H, in_flight, steps, warmup):
+    """Same frames, `in_flight` of them at a time: one context (own workspace) and one stream per slot, so the
+    set-up and binning launches of a frame run beside the evaluation kernel of the frames before it.  Every
+    frame still does all of its work; reported beside `value`, which is measured without any overlap."""
+    ctxs, streams, frames = [], [], []
+    for _ in range(in_flight):
+        c = pb.Context(ctl, device=dev.index)
+        c.set_scene()
+        if het:
+            c.set_grid(*grid)
+        c.upload_segments(segs, root[:3], root[3:])
+        ctxs.append(c); streams.append(torch.cuda.Stream(device=dev))
+        frames.append(torch.zeros((H, W, 3), dtype=torch.float32, device=dev))
+
+    def run(k_frames):
+        for k in range(k_frames):
+            i = k % in_flight
+            ctxs[i].draw_strips_device(frames[i].data_ptr(), 0, 1, (H + 7) // 8, mode=mode, cull=cull,
+                                       stream=streams[i].cuda_stream)
+    run(max(warmup, in_flight))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    same = all(bool(torch.equal(frames[0], f)) for f in frames[1:])
+    for c in ctxs:
+        c.close()
+    rays = W * H * ctl.ssaa * ctl.ssaa
+    return {"frames_in_flight": in_flight, "value": rays * steps / dt / 1e6, "unit": "Mray/s",
+            "ms_per_step": dt / steps * 1e3, "frames_identical": same}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +122,9 @@ def main():
     ap.add_argument("--cull", default="bins", choices=["bins", "lbvh", "scan"],
                     help="how a tile finds its candidate segments (default: screen-space bins)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="frames kept in flight for the extra `pipelined` figure (0: skip it); `value` itself is always "
+                         "measured one frame after the other on one stream")
     args = ap.parse_args()
 
     import torch
@@ -230,6 +266,9 @@ def main():
                 "lbvh_build": (6 * 2 * 12 + 128) * n_segs / (cnt["ms_build"] * 1e-3) / 1e9 if cnt["ms_build"] > 0 else None,
                 "photon_pass": (2 * 80 * n_beams + 2 * 112 * n_segs) / (cnt["ms_emit"] * 1e-3) / 1e9 if cnt["ms_emit"] > 0 else None},
         }
+        if world == 1 and args.in_flight > 1:
+            out["pipelined"] = pipelined_throughput(pb, torch, ctl, dev, segs, root, het, grid, mode, cull, W, H,
+                                                    args.in_flight, args.steps, args.warmup)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, wk, segs, root[:3], root[3:], grid)
         else:
