@@ -105,7 +105,7 @@ int ensure_bin_workspace(pb_ctx* ctx, int tiles, int bin_cap, int item_cap, size
   if (tiles > ctx->ws_tiles) {
     if (ctx->d_tile_u32) PB_HIP(hipFree(ctx->d_tile_u32));
     if (ctx->d_scan_tmp) PB_HIP(hipFree(ctx->d_scan_tmp));
-    ctx->d_tile_u32 = nullptr; ctx->d_scan_tmp = nullptr; ctx->ws_tiles = 0;
+    ctx->d_tile_u32 = nullptr; ctx->d_scan_tmp = nullptr; ctx->ws_tiles = 0; ctx->bins_clean = false;
     PB_HIP(hipMalloc(&ctx->d_tile_u32, sizeof(uint32_t) * (4 + 3 * (size_t)PB_BIN_SUBS) * (size_t)tiles));   // macro tiles <= tiles
     PB_HIP(hipMalloc(&ctx->d_scan_tmp, sizeof(uint32_t) * pb_scan_tmp_words(tiles * PB_BIN_SUBS)));
     ctx->ws_tiles = tiles;
@@ -165,6 +165,9 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
     p.bin_capacity = ctx->ws_bin_cap; p.item_capacity = ctx->ws_item_cap;
     p.fused_queue = (mtiles <= pb_fused_queue_macros()) ? 1 : 0;
     PB_HIP(hipEventRecord(ctx->ev[0], s));
+    if (p.fused_queue && !ctx->bins_clean)
+      PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ctx->ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
+    ctx->bins_clean = false;
     if (!p.fused_queue) {
       PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
       PB_HIP(hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * 4, s));
@@ -173,7 +176,7 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
     }
     rc = pb_launch_ray_setup(p, ctx->count_on, s);
     if (rc != PB_OK) return rc;
-    rc = pb_launch_bin_count(p, s);     // count pass, then (small frames) the whole queue in one block
+    rc = pb_launch_bin_count(p, ctx->count_on, s);     // count pass, then (small frames) the whole queue in one block
     if (rc != PB_OK) return rc;
     if (!p.fused_queue) {
       rc = pb_exclusive_scan_u32(p.sub_count, p.sub_off, mtiles * PB_BIN_SUBS, ctx->d_ctrl + 2, ctx->d_scan_tmp, s);
@@ -199,6 +202,7 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
   p.n_items_host = ctx->ws_items_needed;
   int rc = pb_launch_bin_fill_eval(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
+  ctx->bins_clean = p.fused_queue != 0;      // finalize_kernel has cleared the counters this frame used
   PB_HIP(hipEventRecord(ctx->ev[1], s));
   ctx->ev_valid[0] = true;
   return PB_OK;

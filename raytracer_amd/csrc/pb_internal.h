@@ -196,6 +196,7 @@ struct pb_ctx {
   float* d_grid = nullptr;
   int grid_side = 0;
   int n_seg = 0, cap_seg = 0, frame_mode = 0;
+  bool bins_clean = false;   // every bin counter of the workspace is zero (left so by the last frame's finalize_kernel)
   bool have_segments = false;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   // output staging for the host-pointer render
@@ -263,7 +264,7 @@ int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int on
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);
-int pb_launch_bin_count(const RenderParams& p, hipStream_t s);
+int pb_launch_bin_count(const RenderParams& p, bool count, hipStream_t s);
 int pb_fused_queue_macros(void);
 PB_HDI int pb_macro_count(const RenderParams& p) {
   return ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);

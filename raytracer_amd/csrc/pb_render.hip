@@ -339,9 +339,7 @@ __global__ __launch_bounds__(64) void reduce_kernel(const RenderParams p) {
 // for bit.
 // ---------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
-  const int lane = threadIdx.x;
-  const int group = blockIdx.x;
+PB_DI void ray_setup_body(const RenderParams& p, int group, int lane) {
   const int nsub = p.ssaa * p.ssaa;
   const int tile = group / nsub, sub = group % nsub;
   const int si = sub / p.ssaa, sj = sub % p.ssaa;
@@ -350,14 +348,11 @@ __global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
   const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + (lane >> 3);
   const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
   if (p.fused_queue) {
-    // this launch also clears what the frame accumulates into: the pixel sums and the bin counters
+    // this launch also clears the pixel sums the frame accumulates into (the bin counters are cleared by
+    // the previous frame's finalize_kernel)
     if (sub == 0) {
       unsigned long long* a = p.accum + (size_t)tile * 3 * 64 + lane;   // [tile][channel][lane]
       a[0] = 0ull; a[64] = 0ull; a[128] = 0ull;
-    }
-    if (group == 0) {
-      const int n_macro = pb_macro_count(p);
-      for (int i = lane; i < n_macro; i += 64) { p.sub_count[i] = 0u; p.sub_fill[i] = 0u; }
     }
   }
   Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
@@ -387,6 +382,11 @@ __global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
       if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
     }
   }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
+  ray_setup_body<COUNT>(p, blockIdx.x, threadIdx.x);
 }
 
 // Inward unit normals of the side planes of the pyramid spanned by the sub-rays of the pixel rectangle
@@ -511,12 +511,11 @@ PB_DI void for_each_macro_tile(const RenderParams& p, const float4 A4, const flo
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_LDS_MACROS = 4096;      // 2 x 4096 x 4 B = 32 KB of LDS
 template <bool FILL, bool LDS>
-__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const RenderParams p, int n_macro) {
-  extern __shared__ uint32_t bin_lds[];      // [n_macro] counts, [n_macro] bases
-  uint32_t* lcount = bin_lds;
+PB_DI void bin_body(const RenderParams& p, int n_macro, uint32_t* bin_lds, int block) {
+  uint32_t* lcount = bin_lds;               // [n_macro] counts, [n_macro] bases
   uint32_t* lbase = bin_lds + n_macro;
   const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO, mty = (p.tiles_y + p.macro_h - 1) / p.macro_h;
-  const long long g = (long long)blockIdx.x * BIN_THREADS + threadIdx.x;
+  const long long g = (long long)block * BIN_THREADS + threadIdx.x;
   const int s = (int)(g / PB_BIN_FAN), k = (int)(g % PB_BIN_FAN);
   const bool live = s < p.n_seg;
   float4 A4 = make_float4(0, 0, 1, 0), B4 = A4;
@@ -549,6 +548,12 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const RenderParams p, 
     const uint32_t at = lbase[m] + atomicAdd(&lcount[m], 1u);
     if (at < (uint32_t)p.bin_capacity) p.bin_list[at] = (uint32_t)s;
   });
+}
+
+template <bool FILL, bool LDS>
+__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const RenderParams p, int n_macro) {
+  extern __shared__ uint32_t bin_lds[];
+  bin_body<FILL, LDS>(p, n_macro, bin_lds, blockIdx.x);
 }
 
 // Length of every macro tile's list (sum of its sub-counters).
@@ -599,8 +604,7 @@ __global__ __launch_bounds__(256) void tile_items_kernel(const RenderParams p, i
   p.item_off[slot] = n_items;
 }
 
-__global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, int n_tiles) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+PB_DI void make_items_body(const RenderParams& p, int n_tiles, int t) {
   if (t >= n_tiles) return;
   const uint32_t cnt = p.tile_count[t];
   const uint32_t slices = (cnt + p.slice - 1) / p.slice;
@@ -618,6 +622,29 @@ __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, i
       dst[0] = (uint32_t)(t * nsub + q); dst[1] = list0 + c * p.slice; dst[2] = n; dst[3] = 0u;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, int n_tiles) {
+  make_items_body(p, n_tiles, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Small frames are bound by the number of launches, not by their work: the two binning passes each share
+// a launch with a step that does not depend on them.  Blocks [0, bin_blocks) bin; the others set up rays,
+// one ray group per wave (count pass), or write the evaluation items (fill pass).
+constexpr int ITEM_LANES = 64;
+__global__ __launch_bounds__(BIN_THREADS) void setup_count_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups) {
+  extern __shared__ uint32_t bin_lds[];
+  if ((int)blockIdx.x < bin_blocks) { bin_body<false, true>(p, n_macro, bin_lds, blockIdx.x); return; }
+  const int group = ((int)blockIdx.x - bin_blocks) * (BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
+  if (group < groups) ray_setup_body<false>(p, group, threadIdx.x & 63);
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void fill_items_kernel(const RenderParams p, int n_macro, int bin_blocks, int n_tiles) {
+  extern __shared__ uint32_t bin_lds[];
+  if ((int)blockIdx.x < bin_blocks) { bin_body<true, true>(p, n_macro, bin_lds, blockIdx.x); return; }
+  // one wave per block writes items: spread over many compute units, the scattered 16-byte stores of four
+  // full blocks took as long as the whole binning pass
+  if (threadIdx.x < ITEM_LANES) make_items_body(p, n_tiles, ((int)blockIdx.x - bin_blocks) * ITEM_LANES + (int)threadIdx.x);
 }
 
 // The steps between the two binning passes in one block (frames of up to QUEUE_FUSED_MACROS macro tiles):
@@ -814,6 +841,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
+  if (p.fused_queue && blockIdx.x == 0) {
+    // the bin counters of the next frame start at zero (the queue and the lists have been consumed)
+    const int n_macro = pb_macro_count(p);
+    for (int m = threadIdx.x; m < n_macro; m += blockDim.x) { p.sub_count[m] = 0u; p.sub_fill[m] = 0u; }
+  }
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)p.out_w * p.out_h;
   if (i >= n) return;
@@ -867,9 +899,21 @@ int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream
   return PB_OK;
 }
 
+// Ray set-up and the binning count pass in one launch (frames whose queue is built by one block).
+static bool shares_launches(const RenderParams& p, bool count) { return p.fused_queue && !count && p.n_seg > 0; }
+
 int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
   const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
   if (groups <= 0) return PB_OK;
+  if (shares_launches(p, count)) {
+    const int n_macro = pb_macro_count(p);
+    const int bin_blocks = (int)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
+    const int ray_blocks = (groups + BIN_THREADS / 64 - 1) / (BIN_THREADS / 64);
+    hipLaunchKernelGGL(setup_count_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s,
+                       p, n_macro, bin_blocks, groups);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+  }
   if (count) hipLaunchKernelGGL(ray_setup_kernel<true>, dim3(groups), dim3(64), 0, s, p);
   else hipLaunchKernelGGL(ray_setup_kernel<false>, dim3(groups), dim3(64), 0, s, p);
   PB_HIP(hipGetLastError());
@@ -878,11 +922,11 @@ int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
 
 // count pass, then the two prefix sums (entries per tile -> tile_off, ctrl[2] = total entries;
 // items per tile -> item_off, ctrl[0] = total items)
-int pb_launch_bin_count(const RenderParams& p, hipStream_t s) {
+int pb_launch_bin_count(const RenderParams& p, bool count, hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
   const int n_macro = pb_macro_count(p);
-  if (p.n_seg > 0) {
+  if (p.n_seg > 0 && !shares_launches(p, count)) {
     const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
     if (n_macro <= BIN_LDS_MACROS)
       hipLaunchKernelGGL((bin_kernel<false, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);
@@ -902,14 +946,22 @@ int pb_launch_bin_count(const RenderParams& p, hipStream_t s) {
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
-  if (p.n_seg > 0) {
+  if (shares_launches(p, count)) {
     const int n_macro = pb_macro_count(p);
-    const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
-    if (n_macro <= BIN_LDS_MACROS)
-      hipLaunchKernelGGL((bin_kernel<true, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);
-    else hipLaunchKernelGGL((bin_kernel<true, false>), dim3(blocks), dim3(BIN_THREADS), 0, s, p, n_macro);
+    const int bin_blocks = (int)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
+    const int item_blocks = (tiles + ITEM_LANES - 1) / ITEM_LANES;
+    hipLaunchKernelGGL(fill_items_kernel, dim3(bin_blocks + item_blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s,
+                       p, n_macro, bin_blocks, tiles);
+  } else {
+    if (p.n_seg > 0) {
+      const int n_macro = pb_macro_count(p);
+      const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
+      if (n_macro <= BIN_LDS_MACROS)
+        hipLaunchKernelGGL((bin_kernel<true, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);
+      else hipLaunchKernelGGL((bin_kernel<true, false>), dim3(blocks), dim3(BIN_THREADS), 0, s, p, n_macro);
+    }
+    hipLaunchKernelGGL(make_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
   }
-  hipLaunchKernelGGL(make_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
   // one wave per item when PB_TUNE_WAVES=0: the hardware dispatcher then hands out the queue in order
   int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;
   if (waves > p.item_capacity) waves = p.item_capacity;
