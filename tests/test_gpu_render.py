@@ -165,6 +165,12 @@ def test_large_frame_takes_the_multi_kernel_queue_path(pb):
         lbvh = ctx.draw(cull="lbvh").astype(np.float64)
         bins = ctx.draw(cull="bins").astype(np.float64)
         bins2 = ctx.draw(cull="bins")
+        # a small rectangle next (single-block queue, counters handed over between frames), then the large
+        # frame again: the two paths share the workspace
+        small = [ctx.draw(400, 300, 256, 200, cull="bins") for _ in range(2)]
+        bins3 = ctx.draw(cull="bins")
+    assert np.array_equal(small[0], bins2[300:500, 400:656]) and np.array_equal(small[1], small[0])
+    assert np.array_equal(bins3, bins2)
     np.testing.assert_allclose(lbvh, scan, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(bins, scan, rtol=1e-5, atol=1e-7)
     assert np.array_equal(bins.astype(np.float32), bins2)
