@@ -1,0 +1,93 @@
+"""The BASELINE configurations at their full sizes, checked through properties that need no CPU render of
+the whole frame: the estimate is a sum over segments (additive over any split of the segment set, linear
+in the beam energies), the three candidate searches must agree, strips must reassemble to the frame, and a
+sparse lattice of pixels must match the oracle."""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "cfg2": dict(screen_width=512, screen_height=512, photon_number=10000, bounces=3),
+    "cfg4": dict(screen_width=1024, screen_height=1024, photon_number=100000, bounces=0),
+}
+
+
+@pytest.fixture(scope="module")
+def pb():
+    import raytracer_amd as pb
+    if pb.device_count() < 1:
+        pytest.fail("no GPU visible: the HIP path cannot run (there is no CPU fallback)")
+    return pb
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg4"])
+def test_full_size_homogeneous_properties(pb, name):
+    kw = CONFIGS[name]
+    W, H = kw["screen_width"], kw["screen_height"]
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        n_beams, n_segs = ctx.cast_photon_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        ctx.build_tree()
+        bins = ctx.draw(cull="bins").astype(np.float64)
+        lbvh = ctx.draw(cull="lbvh").astype(np.float64)
+        assert np.array_equal(ctx.draw(cull="bins"), bins.astype(np.float32))          # bit-repeatable
+        # additivity: even- and odd-numbered segments rendered apart
+        parts = []
+        for sel in (segs[0::2], segs[1::2]):
+            ctx.upload_segments(sel, lo, hi)
+            parts.append(ctx.draw(cull="bins").astype(np.float64))
+        # linearity: doubled energies
+        twice = segs.copy(); twice["energy"] *= 2
+        ctx.upload_segments(twice, lo, hi)
+        doubled = ctx.draw(cull="bins").astype(np.float64)
+    assert n_segs > (15000 if name == "cfg2" else 100000)
+    assert np.isfinite(bins).all() and bins.max() > 5.0 and (bins > 0).mean() > 0.3
+    scale = np.maximum(1.0, np.abs(bins))
+    # float32 output: each frame carries one rounding of 6e-8 relative
+    assert (np.abs(lbvh - bins) <= 4e-7 * scale).all()
+    assert (np.abs(parts[0] + parts[1] - bins) <= 4e-7 * scale).all()
+    assert (np.abs(doubled - 2 * bins) <= 4e-7 * 2 * scale).all()
+    # a sparse lattice against the oracle (fast pair arithmetic: the stated tolerance)
+    step = W // 32
+    tri, _ = orc.load_test_model()
+    ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
+                                   segs, lo, hi, step // 2, step // 2, 32, 32, step_x=step, step_y=step)
+    got = bins[step // 2::step, step // 2::step][:32, :32]
+    err = np.abs(got - ref)
+    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), err.max()
+    assert np.sqrt((err ** 2).mean()) <= 1e-4 * max(1.0, ref.max())
+
+
+def test_full_size_heterogeneous_properties(pb):
+    """cfg3: 512^2, 10 000 photons, BOUNCES 3, heterogeneous medium, Integral_73Het."""
+    kw = dict(screen_width=512, screen_height=512, photon_number=10000, bounces=3, heterogeneous=1, one_dimensional=1)
+    sigma, side = pb.make_grid()
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.set_grid(sigma, side)
+        n_beams, n_segs = ctx.cast_photon_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        bins = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)
+        parts = []
+        for sel in (segs[0::2], segs[1::2]):
+            ctx.upload_segments(sel, lo, hi)
+            parts.append(ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64))
+    assert n_segs > 150000 and np.isfinite(bins).all() and bins.max() > 1.0
+    ok = bins < 1000.0                                  # below the fixed-point saturation of single contributions
+    assert ok.mean() > 0.999
+    scale = np.maximum(1.0, np.abs(bins))
+    assert (np.abs(parts[0] + parts[1] - bins)[ok] <= 4e-7 * scale[ok]).all()
+    tri, _ = orc.load_test_model()
+    ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
+                                   segs, lo, hi, 8, 8, 16, 16, step_x=32, step_y=32, mode=orc.MODE_73HET,
+                                   grid_sigma=sigma, side=side)
+    got = bins[8::32, 8::32][:16, :16]
+    small = ref < 1000.0
+    err = np.abs(got - ref)[small]
+    assert (err <= 1e-5 * np.maximum(1.0, np.abs(ref[small]))).all(), err.max()
