@@ -236,6 +236,7 @@ struct pb_ctx {
   bool count_on = false;
   bool precise = false;
   int tune_ablate = 0;
+  int ws_slice = 0;                       // item length chosen for the frame geometry of ws_key (0: not chosen yet)
   int tune_slice = 0, tune_waves = 0;     // 0: defaults chosen per frame   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
   pb_stats stats;
 };
