@@ -199,7 +199,7 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
       // 48 instead of 192, 17 424 segments best at 128.
       const uint32_t mean_list = need_bins / (uint32_t)(mtiles > 0 ? mtiles : 1);
       int want = (int)(mean_list / 6 + 15) / 16 * 16;
-      const int longest = p.strip_stride > 1 ? 96 : 128;
+      const int longest = p.strip_stride >= 8 ? 48 : (p.strip_stride > 1 ? 96 : 128);   // a rank's share of strips has few items
       want = want < 48 ? 48 : (want > longest ? longest : want);
       ctx->ws_slice = want;
       if (want != p.slice) {                 // same capacities, queue rebuilt with the new length
