@@ -1561,8 +1561,9 @@ int orc_lbvh(const pb_segment* segs, int n, uint64_t* keys_out, uint32_t* perm_o
     const pb_segment& sg = segs[perm[i]];
     const float pad = sg.radius * 1.001f + 1e-5f;
     for (int k = 0; k < 3; ++k) {
-      leaf_box[6 * (size_t)i + k] = std::fmin(sg.start[k], sg.end[k]) - pad;
-      leaf_box[6 * (size_t)i + 3 + k] = std::fmax(sg.start[k], sg.end[k]) + pad;
+      // (fixed-radius segments: an adaptive-width one is bounded by a capsule around its gate box instead)
+      leaf_box[6 * (size_t)i + k] = std::fmax(std::fmin(std::fmin(sg.start[k], sg.end[k]) - pad, 1e30f), -1e30f);
+      leaf_box[6 * (size_t)i + 3 + k] = std::fmax(std::fmin(std::fmax(sg.start[k], sg.end[k]) + pad, 1e30f), -1e30f);
     }
   }
   std::vector<int> order; order.reserve(n - 1);

@@ -209,6 +209,12 @@ PB_DI void capsule_box(float4 a, float4 b, float lo[3], float hi[3]) {
   const float pad = a.w * 1.001f + 1e-5f;
   lo[0] = fminf(a.x, b.x) - pad; lo[1] = fminf(a.y, b.y) - pad; lo[2] = fminf(a.z, b.z) - pad;
   hi[0] = fmaxf(a.x, b.x) + pad; hi[1] = fmaxf(a.y, b.y) + pad; hi[2] = fmaxf(a.z, b.z) + pad;
+  // uploaded records may hold infinities or NaN: an infinite bound times a zero plane component is NaN in the
+  // tile test and would cull the whole subtree; keep every bound finite (a NaN record cannot contribute)
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = fmaxf(fminf(lo[k], 1e30f), -1e30f);
+    hi[k] = fmaxf(fminf(hi[k], 1e30f), -1e30f);
+  }
 }
 
 // Node boxes without a bottom-up walk.  A node's box is the union of the leaf boxes over its range of the

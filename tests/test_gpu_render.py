@@ -150,6 +150,60 @@ def test_empty_segment_set_and_errors(pb):
             ctx.draw(0, 0, 65, 1)                    # rectangle exceeds the screen
 
 
+def test_degenerate_segments_are_harmless(pb):
+    """Records a caller can upload but the photon pass never makes: zero length, exactly along +y / -y
+    (findRotationMatrix, Intersections.h:499-513, is singular for -y), behind the camera, zero and huge radius,
+    NaN and infinite coordinates, an inverted gate box.  Mixed into a normal segment set they must neither
+    disturb the other segments' radiance nor depend on how candidates are found."""
+    kw = dict(photon_number=300, bounces=1, screen_width=64, screen_height=64)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        good = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        ctx.build_tree()
+        ctx.set_precise(True)
+        clean = ctx.draw(cull="scan").astype(np.float64)
+        bad = np.zeros(10, pb.SEGMENT_DTYPE)
+        bad["radius"] = 0.03; bad["energy"] = 0.5; bad["seg_id"] = 1
+        bad["cull_lo"] = [-1, -1, 2]; bad["cull_hi"] = [1, 1, 4]
+        P = np.array([0.1, -0.2, 3.0], np.float32)
+        bad["start"] = P; bad["end"] = P + [0.3, 0.4, 0.1]; bad["orig_start"] = P
+        bad["end"][0] = P                                              # zero length
+        bad["end"][1] = P + [0, -0.7, 0]                               # exactly -y
+        bad["end"][2] = P + [0, 0.7, 0]                                # exactly +y
+        bad["start"][3] = [0.2, 0.1, -2.0]; bad["end"][3] = [0.2, 0.3, -1.0]   # behind the camera
+        bad["radius"][4] = 0.0
+        bad["radius"][5] = 10.0
+        bad["start"][6] = [np.nan, 0, 3]
+        bad["end"][7] = [np.inf, 0, 3]
+        bad["cull_lo"][8] = [1, 1, 4]; bad["cull_hi"][8] = [-1, -1, 2]  # inverted gate box: never entered
+        bad["energy"][9] = [np.nan, np.nan, np.nan]; bad["cull_lo"][9] = [5, 5, 5]; bad["cull_hi"][9] = [6, 6, 6]
+        inert = [0, 1, 3, 4, 6, 7, 8, 9]       # cannot contribute: no cylinder, NaN frame, or a gate that is never passed
+        mixed = np.concatenate([good[:100], bad[inert], good[100:]])
+        ctx.upload_segments(mixed, lo, hi)
+        ctx.build_tree()
+        frames = {c: ctx.draw(cull=c).astype(np.float64) for c in ("scan", "lbvh", "bins")}
+        # every record, including the huge and the +y one: the searches must still agree with each other
+        every = np.concatenate([good, bad])
+        ctx.upload_segments(every, lo, hi)
+        ctx.build_tree()
+        all3 = {c: ctx.draw(cull=c).astype(np.float64) for c in ("scan", "lbvh", "bins")}
+    for name, img in frames.items():
+        assert np.isfinite(img).all(), name
+        np.testing.assert_allclose(img, clean, rtol=1e-6, atol=1e-9, err_msg=name)
+    fin = np.isfinite(all3["scan"])
+    assert fin.mean() > 0.99
+    np.testing.assert_allclose(all3["lbvh"][fin], all3["scan"][fin], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(all3["bins"][fin], all3["scan"][fin], rtol=1e-5, atol=1e-7)
+    tri, _ = orc.load_test_model()
+    ref, _ = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
+                                 every, lo, hi, 0, 0, 64, 64)
+    both = fin & np.isfinite(ref)
+    err = np.abs(all3["scan"] - ref)[both]
+    assert both.mean() > 0.99 and (err <= 2e-5 * np.maximum(1.0, np.abs(ref[both]))).all(), err.max()
+
+
 def test_large_frame_takes_the_multi_kernel_queue_path(pb):
     """Frames above 16384 tiles build the evaluation queue with the multi-kernel path (device-wide
     scans) instead of the single-block one: 1160 x 1096 pixels = 145 x 137 tiles.  All three candidate
