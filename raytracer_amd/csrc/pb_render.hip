@@ -326,14 +326,18 @@ __global__ __launch_bounds__(64) void reduce_kernel(const RenderParams p) {
 // ---------------------------------------------------------------------------
 // Binned frame (cull mode 2).  All camera rays leave (0,0,0), so which tiles a segment can touch
 // follows from its projection.
-//  ray_setup_kernel  one wave per ray group: the 64 rays (ClosestIntersection, root gate), stored.
-//  bin_kernel        one lane per segment: appends the segment to the list of every macro tile
-//                    (PB_MACRO x PB_MACRO tiles) whose pyramid its axis can touch; a counting pass, a
-//                    prefix sum, a filling pass.
-//  eval_bins_kernel  a fixed grid of waves pulls items (ray group, slice of its macro tile's list): lanes
-//                    first test 64 candidates at a time against the 8x8 tile's own pyramid and compact the
-//                    survivors in LDS, then every lane evaluates its ray against each survivor.
+//  ray set-up        one wave per ray group: the 64 rays (ClosestIntersection, root gate), stored.
+//  binning           PB_BIN_FAN lanes per segment append it to the list of every macro tile (PB_MACRO x
+//                    macro_h tiles) whose pyramid its axis can touch: a counting pass, list offsets, a
+//                    filling pass.
+//  queue             items = (ray group, slice of its macro tile's list), laid out longest list first.
+//  evaluation        one wave per item: lanes first test 64 candidates at a time against the 8x8 tile's
+//                    own pyramid and compact the survivors in LDS, then every lane evaluates its ray
+//                    against each survivor.
 //  finalize_kernel   fixed-point sums -> current / SSAA.
+// Small frames (queue built by one block) run these as five launches: setup_count_kernel (ray set-up beside
+// the counting pass), queue_build_kernel, fill_items_kernel (filling pass beside the item writing), the
+// evaluation kernel, finalize_kernel.  Large or counted frames use one kernel per step and device-wide scans.
 // The lists are filled with atomics, hence in no fixed order; the radiance is therefore summed in fixed
 // point (PB_FIX_MAGIC), which makes the sum independent of that order and the image reproducible bit
 // for bit.
