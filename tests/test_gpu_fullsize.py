@@ -1,4 +1,4 @@
-"""The BASELINE configurations at their full sizes, checked through properties that need no CPU render of
+"""The benchmark configurations (512^2 with 10 000 photons, 1024^2 with 100 000, the heterogeneous 512^2) at their full sizes, checked through properties that need no CPU render of
 the whole frame: the estimate is a sum over segments (additive over any split of the segment set, linear
 in the beam energies), the three candidate searches must agree, strips must reassemble to the frame, and a
 sparse lattice of pixels must match the oracle."""
