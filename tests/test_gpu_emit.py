@@ -152,3 +152,41 @@ def test_recast_matches_oracle(pb, het):
             assert (rel <= 2e-5).mean() > 0.97 and rel.max() < 2e-2
             assert abs(g_seg - len(oseg)) <= 0.01 * len(oseg) + 4 and g_seg == len(gseg)
             assert n_sc > 50
+
+
+def test_rotated_camera_and_moved_light(pb):
+    """The keyboard controls of the reference (skeleton.cpp:534-610) change theta, the camera position and the
+    light position; every one of them enters through TransformationMatrix (skeleton.cpp:512-532), which the
+    photon pass and the frame both use.  With all three away from their defaults: beams and frame vs the oracle."""
+    kw = dict(photon_number=800, bounces=1, screen_width=96, screen_height=96)
+    def control(mod):
+        c = mod.control_defaults(**kw)
+        c.theta[:] = [0.12, -0.25, 0.06]
+        c.camera[:] = [0.15, 0.1, -2.6, 1.0]
+        c.light_position[:] = [0.3, -0.7, -0.2, 1.0]
+        return c
+    o = orc.Oracle(control(orc))
+    o.cast_photon_beams(rng_kind=1)
+    o.bound_photon_beams()
+    ob = o.beams()
+    with pb.Context(control(pb)) as ctx:
+        ctx.set_scene()
+        nb, ns = ctx.cast_photon_beams()
+        gb = ctx.download_beams()
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        img = ctx.draw(cull="bins").astype(np.float64)
+    assert nb == len(ob) and nb > 700
+    for f in ("photon", "order", "flags", "index_hit"):
+        assert np.array_equal(gb[f], ob[f]), f
+    for f in ("start", "end"):
+        np.testing.assert_allclose(gb[f], ob[f], rtol=0, atol=3e-5, err_msg=f)
+    c = control(orc)
+    m16 = orc.transformation_matrix(tuple(c.theta), tuple(c.camera))
+    assert not np.allclose(m16, orc.transformation_matrix())
+    tri, _ = orc.load_test_model()
+    ref, cnt = orc.render_segments(c, orc.tri_xyz(tri), m16, segs, lo, hi, 0, 0, 96, 96)
+    err = np.abs(img - ref)
+    assert ref.max() > 0.3 and cnt["valid_hits"] > 20000
+    assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), err.max()
+    assert np.sqrt((err ** 2).mean()) <= 1e-4
