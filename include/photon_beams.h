@@ -146,7 +146,7 @@ void pb_destroy(pb_ctx* ctx);
 
 /* The Cornell box of LoadTestModel (TestModelH.h:45-214) in world space:
  * writes 30 triangles as v0,v1,v2 xyz (9 floats each) and, if not NULL, their
- * normals (3 floats each).  Returns the triangle count (30). */
+ * normals (3 floats each).  Returns the triangle count (30), or PB_ERR_CAPACITY if capacity < 30. */
 int pb_load_test_model(float* tri_xyz, float* normals_xyz, int capacity);
 
 /* TransformationMatrix (skeleton.cpp:512-532): column-major 4x4. */

@@ -26,7 +26,8 @@ const int kBlock[10][3] = {{E, B, A}, {E, F, B}, {F, D, B}, {F, H, D}, {H, C, D}
 }  // namespace
 
 extern "C" int pb_load_test_model(float* tri_xyz, float* normals_xyz, int capacity) {
-  if (!tri_xyz || capacity < 30) return PB_ERR_ARG;
+  if (!tri_xyz) return PB_ERR_ARG;
+  if (capacity < 30) return PB_ERR_CAPACITY;
   const float L = 555;                                   // TestModelH.h:65
   const float room_xz[4][2] = {{L, 0}, {0, 0}, {L, L}, {0, L}};
   const float short_xz[4][2] = {{290, 114}, {130, 65}, {240, 272}, {82, 225}};   // :123-126
