@@ -16,18 +16,23 @@
 
 namespace {
 
-// Conservative test: can the capsule (a, b, radius) touch the pyramid of the tile?
-// pl[k] are the four inward unit normals of the side planes (through the origin).
-PB_DI bool capsule_touches_pyramid(const float4 A, const float4 B, const V3 pl[4]) {
+// pl[k] are the four inward unit normals of the side planes (through the origin) of a tile's pyramid.
+// Is some point of the axis a-b within `slack` of all four half-spaces at once?  Clips the parameter
+// interval [0,1] by each plane; tighter than testing the end points plane by plane.
+PB_DI bool axis_touches_pyramid(const float4 A, const float4 B, const V3 pl[4]) {
   const float slack = A.w * 1.001f + 1e-5f;
+  float t0 = -1e-5f, t1 = 1.0f + 1e-5f;
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float da = pl[k].x * A.x + pl[k].y * A.y + pl[k].z * A.z;
-    const float db = pl[k].x * B.x + pl[k].y * B.y + pl[k].z * B.z;
-    ok = ok && (fmaxf(da, db) >= -slack);
+    const float fa = pl[k].x * A.x + pl[k].y * A.y + pl[k].z * A.z + slack;
+    const float fb = pl[k].x * B.x + pl[k].y * B.y + pl[k].z * B.z + slack;
+    ok = ok && !(fa < 0.0f && fb < 0.0f);
+    const float t = fa * fast_rcp(fa - fb);          // only used when fa and fb differ in sign
+    if (fa < 0.0f && fb >= 0.0f) t0 = fmaxf(t0, t - 1e-5f);
+    if (fb < 0.0f && fa >= 0.0f) t1 = fminf(t1, t + 1e-5f);
   }
-  return ok;
+  return ok && (t0 <= t1);
 }
 
 // ---------------------------------------------------------------------------
@@ -174,8 +179,8 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
           const bool t0 = box_touches_pyramid(nd.lo0, nd.hi0, pl);
           const bool t1 = box_touches_pyramid(nd.lo1, nd.hi1, pl);
           in0 = t0 && c0 >= 0; in1 = t1 && c1 >= 0;
-          if (t0 && c0 < 0) { lf0 = capsule_touches_pyramid(p.lbvh_sA[~c0], p.lbvh_sB[~c0], pl); if (lf0) v0 = p.lbvh_perm[~c0]; }
-          if (t1 && c1 < 0) { lf1 = capsule_touches_pyramid(p.lbvh_sA[~c1], p.lbvh_sB[~c1], pl); if (lf1) v1 = p.lbvh_perm[~c1]; }
+          if (t0 && c0 < 0) { lf0 = axis_touches_pyramid(p.lbvh_sA[~c0], p.lbvh_sB[~c0], pl); if (lf0) v0 = p.lbvh_perm[~c0]; }
+          if (t1 && c1 < 0) { lf1 = axis_touches_pyramid(p.lbvh_sA[~c1], p.lbvh_sB[~c1], pl); if (lf1) v1 = p.lbvh_perm[~c1]; }
         }
         const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
         const int n0 = __builtin_popcountll(m0);
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
       for (int base = 0; base < p.n_seg; base += 64) {
         const int s = base + lane;
         bool touch = false;
-        if (s < p.n_seg) touch = capsule_touches_pyramid(p.capA[s], p.capB[s], pl);
+        if (s < p.n_seg) touch = axis_touches_pyramid(p.capA[s], p.capB[s], pl);
         append_candidates(p, w, touch, (uint32_t)s, lane);
       }
     }
@@ -405,24 +410,6 @@ PB_DI void pixel_rect_planes(const RenderParams& p, int px0, int px1, int py0, i
   pl[1] = normalize3(v3(-p.focal, 0.0f, xr));
   pl[2] = normalize3(v3(0.0f, p.focal, -yt));
   pl[3] = normalize3(v3(0.0f, -p.focal, yb));
-}
-
-// Is some point of the axis a-b within `slack` of all four half-spaces at once?  Clips the parameter
-// interval [0,1] by each plane; tighter than testing the end points plane by plane.
-PB_DI bool axis_touches_pyramid(const float4 A, const float4 B, const V3 pl[4]) {
-  const float slack = A.w * 1.001f + 1e-5f;
-  float t0 = -1e-5f, t1 = 1.0f + 1e-5f;
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float fa = pl[k].x * A.x + pl[k].y * A.y + pl[k].z * A.z + slack;
-    const float fb = pl[k].x * B.x + pl[k].y * B.y + pl[k].z * B.z + slack;
-    ok = ok && !(fa < 0.0f && fb < 0.0f);
-    const float t = fa * fast_rcp(fa - fb);          // only used when fa and fb differ in sign
-    if (fa < 0.0f && fb >= 0.0f) t0 = fmaxf(t0, t - 1e-5f);
-    if (fb < 0.0f && fa >= 0.0f) t1 = fminf(t1, t + 1e-5f);
-  }
-  return ok && (t0 <= t1);
 }
 
 struct TileRect { int x0, x1, y0, y1; };   // inclusive; empty if x1 < x0
