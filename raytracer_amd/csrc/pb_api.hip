@@ -360,14 +360,19 @@ int pb_create(const pb_control* control, int device, pb_ctx** out) {
   ctx->device = device;
   std::memset(&ctx->stats, 0, sizeof(ctx->stats));
   *out = nullptr;
-  PB_HIP(hipSetDevice(device));
-  PB_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  for (int i = 0; i < 8; ++i) PB_HIP(hipEventCreate(&ctx->ev[i]));
-  PB_HIP(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * PB_CNT_N));
-  PB_HIP(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N));
-  PB_HIP(hipMalloc(&ctx->d_matrix, sizeof(float) * 16));
-  PB_HIP(hipMalloc(&ctx->d_ctrl, sizeof(uint32_t) * 4));
-  PB_HIP(hipHostMalloc(&ctx->h_ctrl, sizeof(uint32_t) * 4));
+  auto set_up = [&]() -> int {
+    PB_HIP(hipSetDevice(device));
+    PB_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) PB_HIP(hipEventCreate(&ctx->ev[i]));
+    PB_HIP(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * PB_CNT_N));
+    PB_HIP(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N));
+    PB_HIP(hipMalloc(&ctx->d_matrix, sizeof(float) * 16));
+    PB_HIP(hipMalloc(&ctx->d_ctrl, sizeof(uint32_t) * 4));
+    PB_HIP(hipHostMalloc(&ctx->h_ctrl, sizeof(uint32_t) * 4));
+    return PB_OK;
+  };
+  const int rc_set_up = set_up();
+  if (rc_set_up != PB_OK) { pb_destroy(ctx); return rc_set_up; }      // releases whatever was created
   if (const char* e = std::getenv("PB_TUNE_SLICE")) { int v = std::atoi(e); if (v >= 32 && v <= PB_SLICE) ctx->tune_slice = v; }
   if (const char* e = std::getenv("PB_TUNE_WAVES")) { int v = std::atoi(e); if (v == 0 || (v >= 64 && v <= (1 << 20))) ctx->tune_waves = v; }
   if (const char* e = std::getenv("PB_TUNE_ABLATE")) ctx->tune_ablate = std::atoi(e);
@@ -561,6 +566,7 @@ int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbv
 
 int pb_render(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh, float* rgb_out) {
   if (!ctx || !rgb_out || w <= 0 || h <= 0) { pb_set_error("pb_render: bad argument"); return PB_ERR_ARG; }
+  if (x0 < 0 || y0 < 0 || x0 + w > ctx->ctl.screen_width || y0 + h > ctx->ctl.screen_height) { pb_set_error("pb_render: rectangle exceeds the screen"); return PB_ERR_ARG; }
   int rc = ensure_device(ctx);
   if (rc != PB_OK) return rc;
   size_t need = (size_t)w * h * 3;
