@@ -57,12 +57,32 @@ struct ChunkWriter {
   uint32_t count;     // wave-uniform
   int prev;           // last chunk written for this group, -1 if none
   int group;
+  uint32_t next = 0, left = 0, batch = 1;   // chunk ids reserved from the pool and not used yet
 };
 
+// Chunk ids come from one device-wide counter, and same-address atomics run at about 12 ns each on this
+// chip: a group reserves 1, 2, 4, ... ids at a time (one atomic per reservation, at most as many ids unused
+// as used).  Unused ids are closed as empty chunks, which eval_kernel skips.
+PB_DI void close_unused_chunks(const RenderParams& p, int group, uint32_t next, uint32_t left, int tid, int n_threads) {
+  for (uint32_t k = tid; k < left; k += n_threads) {
+    const uint32_t c = next + k;
+    if (c < (uint32_t)p.chunk_capacity) {
+      uint32_t* dst = p.chunks + (size_t)c * PB_CHUNK_WORDS;
+      dst[0] = (uint32_t)group; dst[1] = 0u; dst[2] = 0xffffffffu; dst[3] = 0u;
+    }
+  }
+}
+
 PB_DI void flush_chunk(const RenderParams& p, ChunkWriter& w, uint32_t n, int lane) {
-  uint32_t c = 0;
-  if (lane == 0) c = atomicAdd(&p.ctrl[0], 1u);
-  c = __builtin_amdgcn_readfirstlane(c);
+  if (w.left == 0) {
+    uint32_t first = 0;
+    if (lane == 0) first = atomicAdd(&p.ctrl[0], w.batch);
+    w.next = __builtin_amdgcn_readfirstlane(first);
+    w.left = w.batch;
+    w.batch *= 2;
+  }
+  const uint32_t c = w.next;
+  w.next++; w.left--;
   if (c < (uint32_t)p.chunk_capacity) {
     uint32_t* dst = p.chunks + (size_t)c * PB_CHUNK_WORDS;
     if (lane == 0) { dst[0] = (uint32_t)w.group; dst[1] = n; dst[2] = (uint32_t)w.prev; dst[3] = 0u; }
@@ -200,9 +220,159 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
       }
     }
     if (w.count > 0) flush_chunk(p, w, w.count, lane);
+    close_unused_chunks(p, group, w.next, w.left, lane, 64);
   }
   if (lane == 0) p.group_last[group] = w.prev;
   if (COUNT) {
+    unsigned long long v[3] = {in_image ? 1ull : 0ull, hit_scene ? 1ull : 0ull, c_gated};
+    const int slot[3] = {PB_CNT_RAYS, PB_CNT_RAYS_HIT, PB_CNT_GATED};
+    for (int k = 0; k < 3; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&p.counters[slot[k]], x);
+    }
+  }
+}
+
+// LBVH traversal with CULL_WAVES waves per tile.  The length of a one-wave traversal is set by its busiest
+// tile: the tile over the light source meets every first-cast beam, and one wave pops those leaves 64 at a
+// time.  Here the block's waves share the stack and the candidate buffer: up to CULL_THREADS nodes are popped
+// per step, pushes and candidates are compacted across the block (wave ballots, then per-wave offsets
+// through LDS), in thread order, so the candidate list is the same on every run.
+constexpr int CULL_WAVES = 4;
+constexpr int CULL_THREADS = 64 * CULL_WAVES;
+constexpr int CULL_BUF = PB_CHUNK + 2 * CULL_THREADS;
+
+struct BlockCounts { int n[2][CULL_WAVES]; };
+
+// exclusive offset of this thread's wave and the block total, for two flag sets at once
+PB_DI void block_offsets(BlockCounts& sc, unsigned long long m0, unsigned long long m1, int wave, int lane,
+                         int& base0, int& base1, int& total0, int& total1) {
+  if (lane == 0) { sc.n[0][wave] = __builtin_popcountll(m0); sc.n[1][wave] = __builtin_popcountll(m1); }
+  __syncthreads();
+  base0 = base1 = total0 = total1 = 0;
+#pragma unroll
+  for (int w = 0; w < CULL_WAVES; ++w) {
+    if (w < wave) { base0 += sc.n[0][w]; base1 += sc.n[1][w]; }
+    total0 += sc.n[0][w]; total1 += sc.n[1][w];
+  }
+  __syncthreads();     // sc is rewritten by the next call
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(CULL_THREADS) void cull_lbvh_block_kernel(const RenderParams p) {
+  __shared__ uint32_t buf[CULL_BUF];
+  __shared__ int stack[PB_STACK_CAP + 2 * CULL_THREADS];
+  __shared__ BlockCounts sc;
+  __shared__ uint32_t s_chunk;
+  __shared__ int s_any;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int group = blockIdx.x;
+  const int nsub = p.ssaa * p.ssaa;
+  const int tile = group / nsub, sub = group % nsub;
+  const int si = sub / p.ssaa, sj = sub % p.ssaa;
+  const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
+  bool in_image = false, hit_scene = false;
+  Ray r;
+  r.active = false; r.maxd = -1.0f; r.dn = v3(0, 0, 1);
+  if (wave == 0) {
+    // the tile's 64 rays, as in cull_kernel
+    const int lx = lane & 7, ly = lane >> 3;
+    const int ox = 8 * tx + lx, oy = 8 * tk + ly;
+    const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + ly;
+    in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
+    r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
+    r.active = r.active && in_image;
+    hit_scene = r.active;
+    r.active = r.active && box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd);
+    if (!r.active) r.maxd = -1.0f;
+    float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+    rr[0 * 64 + lane] = r.l.x; rr[1 * 64 + lane] = r.l.y; rr[2 * 64 + lane] = r.l.z;
+    rr[3 * 64 + lane] = r.dn.x; rr[4 * 64 + lane] = r.dn.y; rr[5 * 64 + lane] = r.dn.z;
+    rr[6 * 64 + lane] = r.maxd; rr[7 * 64 + lane] = 0.0f;
+    rr[8 * 64 + lane] = r.d1.x; rr[9 * 64 + lane] = r.d1.y; rr[10 * 64 + lane] = r.d1.z; rr[11 * 64 + lane] = 0.0f;
+    const bool any = __ballot(r.active) != 0ull;
+    if (lane == 0) { s_any = any ? 1 : 0; stack[0] = 0; }
+  }
+  __syncthreads();
+  int prev = -1;                       // last chunk written for this group (block-uniform)
+  if (s_any) {
+    V3 pl[4];
+    tile_planes(p, tx, tk, pl);
+    int top = 1, count = 0;            // block-uniform
+    uint32_t next = 0, left = 0, batch = 1;
+    // emits buf[from .. from + n) as one chunk
+    auto flush = [&](int from, int n) {
+      if (left == 0) {
+        if (tid == 0) s_chunk = atomicAdd(&p.ctrl[0], batch);
+        __syncthreads();
+        next = s_chunk;
+        left = batch;
+        batch *= 2;
+      }
+      const uint32_t c = next;
+      next++; left--;
+      if (c < (uint32_t)p.chunk_capacity) {
+        uint32_t* dst = p.chunks + (size_t)c * PB_CHUNK_WORDS;
+        if (tid == 0) { dst[0] = (uint32_t)group; dst[1] = (uint32_t)n; dst[2] = (uint32_t)prev; dst[3] = 0u; }
+        for (int k = tid; k < n; k += CULL_THREADS) dst[4 + k] = buf[from + k];
+        prev = (int)c;
+      }
+      __syncthreads();                 // s_chunk and buf may be rewritten
+    };
+    while (top > 0) {
+      int k = top < CULL_THREADS ? top : CULL_THREADS;
+      if (top + k > PB_STACK_CAP) { k = PB_STACK_CAP - top; if (k < 1) k = 1; }   // keep pushes inside the slack
+      const int node = (tid < k) ? stack[top - k + tid] : -1;
+      top -= k;
+      __syncthreads();
+      bool in0 = false, in1 = false, lf0 = false, lf1 = false;
+      int c0 = 0, c1 = 0;
+      uint32_t v0 = 0, v1 = 0;
+      if (node >= 0) {
+        const LbvhNode nd = p.lbvh_nodes[node];
+        c0 = nd.child0; c1 = nd.child1;
+        const bool t0 = box_touches_pyramid(nd.lo0, nd.hi0, pl);
+        const bool t1 = box_touches_pyramid(nd.lo1, nd.hi1, pl);
+        in0 = t0 && c0 >= 0; in1 = t1 && c1 >= 0;
+        if (t0 && c0 < 0) { lf0 = axis_touches_pyramid(p.lbvh_sA[~c0], p.lbvh_sB[~c0], pl); if (lf0) v0 = p.lbvh_perm[~c0]; }
+        if (t1 && c1 < 0) { lf1 = axis_touches_pyramid(p.lbvh_sA[~c1], p.lbvh_sB[~c1], pl); if (lf1) v1 = p.lbvh_perm[~c1]; }
+      }
+      int b0, b1, n0, n1;
+      unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
+      block_offsets(sc, m0, m1, wave, lane, b0, b1, n0, n1);
+      if (in0) stack[top + b0 + (int)lanes_below(m0)] = c0;
+      if (in1) stack[top + n0 + b1 + (int)lanes_below(m1)] = c1;
+      top += n0 + n1;
+      m0 = __ballot(lf0); m1 = __ballot(lf1);
+      block_offsets(sc, m0, m1, wave, lane, b0, b1, n0, n1);
+      if (lf0) buf[count + b0 + (int)lanes_below(m0)] = v0;
+      if (lf1) buf[count + n0 + b1 + (int)lanes_below(m1)] = v1;
+      count += n0 + n1;
+      __syncthreads();
+      int head = 0;
+      while (count - head >= PB_CHUNK) { flush(head, PB_CHUNK); head += PB_CHUNK; }
+      if (head > 0) {
+        const int rest = count - head;           // < PB_CHUNK <= CULL_THREADS
+        uint32_t keep = 0;
+        if (tid < rest) keep = buf[head + tid];
+        __syncthreads();
+        if (tid < rest) buf[tid] = keep;
+        count = rest;
+        __syncthreads();
+      }
+    }
+    if (count > 0) flush(0, count);
+    close_unused_chunks(p, group, next, left, tid, CULL_THREADS);
+  }
+  if (tid == 0) p.group_last[group] = prev;
+  if (COUNT && wave == 0) {
+    unsigned long long c_gated = 0;
+    if (s_any)
+      for (int sidx = 0; sidx < p.n_seg; ++sidx) {
+        const SegFrame& f = p.frames[sidx];
+        c_gated += box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd) ? 1 : 0;
+      }
     unsigned long long v[3] = {in_image ? 1ull : 0ull, hit_scene ? 1ull : 0ull, c_gated};
     const int slot[3] = {PB_CNT_RAYS, PB_CNT_RAYS_HIT, PB_CNT_GATED};
     for (int k = 0; k < 3; ++k) {
@@ -266,6 +436,7 @@ __global__ __launch_bounds__(64) void eval_kernel(const RenderParams p) {
     const PB_CONST_AS uint32_t* ch = pb_uniform(p.chunks + (size_t)c * PB_CHUNK_WORDS);
     const int group = (int)ch[0];
     const int n = (int)ch[1];
+    if (n == 0) continue;               // an id its group reserved and did not need; in no group's list
     const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
     Ray r;
     r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
@@ -859,9 +1030,9 @@ int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
   const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
   if (groups <= 0) return PB_OK;
   const bool lbvh = p.lbvh_n >= 2;
-  if (count && lbvh) hipLaunchKernelGGL((cull_kernel<true, true>), dim3(groups), dim3(64), 0, s, p);
+  if (count && lbvh) hipLaunchKernelGGL(cull_lbvh_block_kernel<true>, dim3(groups), dim3(CULL_THREADS), 0, s, p);
   else if (count) hipLaunchKernelGGL((cull_kernel<true, false>), dim3(groups), dim3(64), 0, s, p);
-  else if (lbvh) hipLaunchKernelGGL((cull_kernel<false, true>), dim3(groups), dim3(64), 0, s, p);
+  else if (lbvh) hipLaunchKernelGGL(cull_lbvh_block_kernel<false>, dim3(groups), dim3(CULL_THREADS), 0, s, p);
   else hipLaunchKernelGGL((cull_kernel<false, false>), dim3(groups), dim3(64), 0, s, p);
   PB_HIP(hipGetLastError());
   return PB_OK;
