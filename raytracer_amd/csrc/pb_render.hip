@@ -36,14 +36,15 @@ PB_DI bool axis_touches_pyramid(const float4 A, const float4 B, const V3 pl[4]) 
 }
 
 // ---------------------------------------------------------------------------
-// Frame = three launches.
-//  cull_kernel    one wave per ray group (an 8x8 tile, one sub-sample): sets up the 64 rays, stores them,
-//                 finds the segments whose capsule can touch the tile pyramid (one segment or LBVH node per
-//                 lane) and appends their indices to chunks of PB_CHUNK candidates taken from a pool.
-//  eval_kernel    a fixed grid of waves pulls chunks from a work counter; a wave evaluates the 64 rays of
-//                 the chunk's group against the chunk's candidates and stores 64 x 3 partial sums.  A tile
-//                 over the light source has two orders of magnitude more candidates than the median tile;
-//                 cutting it into chunks is what keeps one wave from serialising it.
+// Ordered frame (cull modes 0 and 1) = three launches.
+//  cull           per ray group (an 8x8 tile, one sub-sample): sets up the 64 rays, stores them, finds the
+//                 segments whose axis can come within their radius of the tile pyramid - cull_scan_kernel
+//                 tests every segment, one per lane; cull_lbvh_block_kernel walks the LBVH, one node per
+//                 lane - and appends their indices to chunks of PB_CHUNK candidates taken from a pool.
+//  eval_kernel    one wave per chunk: evaluates the 64 rays of the chunk's group against the chunk's
+//                 candidates and stores 64 x 3 partial sums.  A tile over the light source has two orders
+//                 of magnitude more candidates than the median tile; cutting it into chunks is what keeps
+//                 one wave from serialising it.
 //  reduce_kernel  one wave per tile adds the partial sums of the tile's chunks in list order (the same
 //                 order every run) and writes current / SSAA.
 // ---------------------------------------------------------------------------
@@ -137,10 +138,9 @@ PB_DI void tile_planes(const RenderParams& p, int tx, int tk, V3 pl[4]) {
   pl[3] = normalize3(v3(0.0f, -p.focal, yb));
 }
 
-template <bool COUNT, bool LBVH>
-__global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
+template <bool COUNT>
+__global__ __launch_bounds__(64) void cull_scan_kernel(const RenderParams p) {
   __shared__ uint32_t buf[PB_CHUNK + 64];
-  __shared__ int stack[LBVH ? (PB_STACK_CAP + 128) : 1];
   const int lane = threadIdx.x;
   const int group = blockIdx.x;
   const int nsub = p.ssaa * p.ssaa;
@@ -177,47 +177,11 @@ __global__ __launch_bounds__(64) void cull_kernel(const RenderParams p) {
         c_gated += box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd) ? 1 : 0;
       }
     }
-    if (LBVH) {
-      // Wave-cooperative traversal: up to 64 nodes are popped per step, one per lane; a lane tests both
-      // child boxes of its node, inner children are pushed with ballot compaction, leaf children are
-      // tested as capsules and appended to the candidate list.
-      int top = 1;
-      if (lane == 0) stack[0] = 0;
-      __syncthreads();
-      while (top > 0) {
-        int k = top < 64 ? top : 64;
-        if (top + k > PB_STACK_CAP) { k = PB_STACK_CAP - top; if (k < 1) k = 1; }   // keep pushes inside the slack
-        const int node = (lane < k) ? stack[top - k + lane] : -1;
-        top -= k;
-        __syncthreads();
-        bool in0 = false, in1 = false, lf0 = false, lf1 = false;
-        int c0 = 0, c1 = 0;
-        uint32_t v0 = 0, v1 = 0;
-        if (node >= 0) {
-          const LbvhNode nd = p.lbvh_nodes[node];
-          c0 = nd.child0; c1 = nd.child1;
-          const bool t0 = box_touches_pyramid(nd.lo0, nd.hi0, pl);
-          const bool t1 = box_touches_pyramid(nd.lo1, nd.hi1, pl);
-          in0 = t0 && c0 >= 0; in1 = t1 && c1 >= 0;
-          if (t0 && c0 < 0) { lf0 = axis_touches_pyramid(p.lbvh_sA[~c0], p.lbvh_sB[~c0], pl); if (lf0) v0 = p.lbvh_perm[~c0]; }
-          if (t1 && c1 < 0) { lf1 = axis_touches_pyramid(p.lbvh_sA[~c1], p.lbvh_sB[~c1], pl); if (lf1) v1 = p.lbvh_perm[~c1]; }
-        }
-        const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
-        const int n0 = __builtin_popcountll(m0);
-        if (in0) stack[top + (int)lanes_below(m0)] = c0;
-        if (in1) stack[top + n0 + (int)lanes_below(m1)] = c1;
-        top += n0 + __builtin_popcountll(m1);
-        append_candidates(p, w, lf0, v0, lane);
-        append_candidates(p, w, lf1, v1, lane);
-        __syncthreads();
-      }
-    } else {
-      for (int base = 0; base < p.n_seg; base += 64) {
-        const int s = base + lane;
-        bool touch = false;
-        if (s < p.n_seg) touch = axis_touches_pyramid(p.capA[s], p.capB[s], pl);
-        append_candidates(p, w, touch, (uint32_t)s, lane);
-      }
+    for (int base = 0; base < p.n_seg; base += 64) {
+      const int s = base + lane;
+      bool touch = false;
+      if (s < p.n_seg) touch = axis_touches_pyramid(p.capA[s], p.capB[s], pl);
+      append_candidates(p, w, touch, (uint32_t)s, lane);
     }
     if (w.count > 0) flush_chunk(p, w, w.count, lane);
     close_unused_chunks(p, group, w.next, w.left, lane, 64);
@@ -276,7 +240,7 @@ __global__ __launch_bounds__(CULL_THREADS) void cull_lbvh_block_kernel(const Ren
   Ray r;
   r.active = false; r.maxd = -1.0f; r.dn = v3(0, 0, 1);
   if (wave == 0) {
-    // the tile's 64 rays, as in cull_kernel
+    // the tile's 64 rays, as in cull_scan_kernel
     const int lx = lane & 7, ly = lane >> 3;
     const int ox = 8 * tx + lx, oy = 8 * tk + ly;
     const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + ly;
@@ -1031,9 +995,9 @@ int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
   if (groups <= 0) return PB_OK;
   const bool lbvh = p.lbvh_n >= 2;
   if (count && lbvh) hipLaunchKernelGGL(cull_lbvh_block_kernel<true>, dim3(groups), dim3(CULL_THREADS), 0, s, p);
-  else if (count) hipLaunchKernelGGL((cull_kernel<true, false>), dim3(groups), dim3(64), 0, s, p);
+  else if (count) hipLaunchKernelGGL(cull_scan_kernel<true>, dim3(groups), dim3(64), 0, s, p);
   else if (lbvh) hipLaunchKernelGGL(cull_lbvh_block_kernel<false>, dim3(groups), dim3(CULL_THREADS), 0, s, p);
-  else hipLaunchKernelGGL((cull_kernel<false, false>), dim3(groups), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(cull_scan_kernel<false>, dim3(groups), dim3(64), 0, s, p);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }
