@@ -385,7 +385,8 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
-                  ctx->d_het, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_rays, ctx->d_group_last,
+                  ctx->d_het, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
+                  ctx->d_emit_tmp[1], ctx->d_rays, ctx->d_group_last,
                   ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->d_tile_u32, ctx->d_bin_list, ctx->d_items, ctx->d_accum,
                   ctx->d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
                   ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};

@@ -12,6 +12,8 @@
 #include <cstddef>
 #include <cstring>
 
+#include <utility>
+
 #include "pb_internal.h"
 #include "pb_philox.h"
 #include "pb_geom.h"
@@ -472,10 +474,19 @@ __global__ __launch_bounds__(1024) void root_box_kernel(const float* __restrict_
   }
 }
 
-struct TmpBuffers {
-  uint32_t* a = nullptr;
-  ~TmpBuffers() { if (a) (void)hipFree(a); }
-};
+// Scratch of the photon pass lives in the context and only grows: a stop-motion loop re-casts every frame,
+// and an allocation or a free costs more than the kernels of a small pass.
+int emit_scratch(pb_ctx* ctx, int which, size_t words, uint32_t** out) {
+  if (words > ctx->emit_tmp_words[which]) {
+    if (ctx->d_emit_tmp[which]) PB_HIP(hipFree(ctx->d_emit_tmp[which]));
+    ctx->d_emit_tmp[which] = nullptr; ctx->emit_tmp_words[which] = 0;
+    const size_t want = words + words / 4;
+    PB_HIP(hipMalloc(&ctx->d_emit_tmp[which], sizeof(uint32_t) * want));
+    ctx->emit_tmp_words[which] = want;
+  }
+  *out = ctx->d_emit_tmp[which];
+  return PB_OK;
+}
 
 }  // namespace
 
@@ -488,16 +499,17 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   // scratch: cnt_const[n] cnt_scatt[n] off_const[n] off_scatt[n] totals[4] dropped[1] root[6] + scan tmp
   const size_t n = (size_t)n_photons;
   const size_t scan_words = pb_scan_tmp_words(n_photons > 0 ? n_photons : 1);
-  TmpBuffers tmp;
   const size_t head = 4 * n + 16 + 6 * ROOT_BOX_BLOCKS;
-  PB_HIP(hipMalloc(&tmp.a, sizeof(uint32_t) * (head + scan_words)));
-  PB_HIP(hipMemsetAsync(tmp.a, 0, sizeof(uint32_t) * (head + scan_words), s));
-  uint32_t* cnt_const = tmp.a; uint32_t* cnt_scatt = tmp.a + n;
-  uint32_t* off_const = tmp.a + 2 * n; uint32_t* off_scatt = tmp.a + 3 * n;
-  uint32_t* totals = tmp.a + 4 * n;            // [0] n_const [1] n_scatt [2] n_seg [3] dropped
-  float* d_root = (float*)(tmp.a + 4 * n + 8); // 6 floats
-  float* d_root_partial = (float*)(tmp.a + 4 * n + 16);   // 6 floats per block of the first root-box launch
-  uint32_t* scan_tmp = tmp.a + head;
+  uint32_t* tmp_a = nullptr;
+  int rc = emit_scratch(ctx, 0, head + scan_words, &tmp_a);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipMemsetAsync(tmp_a, 0, sizeof(uint32_t) * (head + scan_words), s));
+  uint32_t* cnt_const = tmp_a; uint32_t* cnt_scatt = tmp_a + n;
+  uint32_t* off_const = tmp_a + 2 * n; uint32_t* off_scatt = tmp_a + 3 * n;
+  uint32_t* totals = tmp_a + 4 * n;            // [0] n_const [1] n_scatt [2] n_seg [3] dropped
+  float* d_root = (float*)(tmp_a + 4 * n + 8); // 6 floats
+  float* d_root_partial = (float*)(tmp_a + 4 * n + 16);   // 6 floats per block of the first root-box launch
+  uint32_t* scan_tmp = tmp_a + head;
 
   EmitParams ep;
   std::memset(&ep, 0, sizeof(ep));
@@ -514,7 +526,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
     else hipLaunchKernelGGL((emit_kernel<false, false>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
   }
   PB_HIP(hipGetLastError());
-  int rc = pb_exclusive_scan_u32(cnt_const, off_const, n_photons, totals + 0, scan_tmp, s);
+  rc = pb_exclusive_scan_u32(cnt_const, off_const, n_photons, totals + 0, scan_tmp, s);
   if (rc != PB_OK) return rc;
   rc = pb_exclusive_scan_u32(cnt_scatt, off_scatt, n_photons, totals + 1, scan_tmp, s);
   if (rc != PB_OK) return rc;
@@ -523,12 +535,15 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   PB_HIP(hipStreamSynchronize(s));
   const int nc = recast ? n_photons : (int)h_tot[0], ns = (int)h_tot[1], nb = nc + ns;
 
-  struct BeamHolder {                    // frees the new list if an error returns before it is adopted
-    pb_beam* p = nullptr;
-    ~BeamHolder() { if (p) (void)hipFree(p); }
-  } holder;
-  PB_HIP(hipMalloc(&holder.p, sizeof(pb_beam) * (size_t)(nb > 0 ? nb : 1)));
-  pb_beam* new_beams = holder.p;
+  // the new list goes into the spare buffer (a re-cast reads the old list while it writes the new one)
+  const size_t want_beams = (size_t)(nb > 0 ? nb : 1);
+  if (want_beams > ctx->cap_beams_spare) {
+    if (ctx->d_beams_spare) PB_HIP(hipFree(ctx->d_beams_spare));
+    ctx->d_beams_spare = nullptr; ctx->cap_beams_spare = 0;
+    PB_HIP(hipMalloc(&ctx->d_beams_spare, sizeof(pb_beam) * (want_beams + want_beams / 8)));
+    ctx->cap_beams_spare = want_beams + want_beams / 8;
+  }
+  pb_beam* new_beams = ctx->d_beams_spare;
   if (recast && nc > 0)
     PB_HIP(hipMemcpyAsync(new_beams, old_beams, sizeof(pb_beam) * (size_t)nc, hipMemcpyDeviceToDevice, s));
   ep.beams_const = new_beams; ep.beams_scatt = new_beams + nc;
@@ -538,18 +553,16 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
     else hipLaunchKernelGGL((emit_kernel<true, false>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
   }
   PB_HIP(hipGetLastError());
-  PB_HIP(hipStreamSynchronize(s));     // the old list is read by the copy and by the re-cast lanes
-  if (ctx->d_beams) PB_HIP(hipFree(ctx->d_beams));
-  ctx->d_beams = new_beams;
-  holder.p = nullptr;
+  // adopt the new list; the old one becomes the spare (stream order keeps its readers ahead of the next writer)
+  std::swap(ctx->d_beams, ctx->d_beams_spare);
+  std::swap(ctx->cap_beams, ctx->cap_beams_spare);
   ctx->n_beams_const = nc; ctx->n_beams_scatt = ns;
 
   // segments
   uint32_t* seg_buf = nullptr;
-  TmpBuffers tmp2;
   const size_t scan_words2 = pb_scan_tmp_words(nb > 0 ? nb : 1);
-  PB_HIP(hipMalloc(&tmp2.a, sizeof(uint32_t) * (2 * (size_t)(nb > 0 ? nb : 1) + scan_words2)));
-  seg_buf = tmp2.a;
+  rc = emit_scratch(ctx, 1, 2 * (size_t)(nb > 0 ? nb : 1) + scan_words2, &seg_buf);
+  if (rc != PB_OK) return rc;
   uint32_t* seg_count = seg_buf; uint32_t* seg_offset = seg_buf + (nb > 0 ? nb : 1);
   uint32_t* scan_tmp2 = seg_buf + 2 * (size_t)(nb > 0 ? nb : 1);
   BoundParams bp;
