@@ -63,7 +63,8 @@ def cpu_baseline(args, control_kwargs, segs, root_lo, root_hi, grid=None):
                                  grid_sigma=None if grid is None else grid[0], side=0 if grid is None else grid[1])
     dt = time.perf_counter() - t0
     return {"value": cnt["rays"] / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
-            "sample": f"every {step}th pixel in x and y of the same frame ({nx}x{ny} rays, {dt:.1f} s), "
+            "sample": (f"every pixel of the same frame ({nx}x{ny} rays, {dt:.1f} s), " if step == 1 else
+                       f"every {step}th pixel in x and y of the same frame ({nx}x{ny} rays, {dt:.1f} s), ") +
                       f"flat scan of all {len(segs)} segments per ray (the reference's BuildTree diverges "
                       f"above ~5200 photons, so its own tree cannot be built for this workload)",
             "n_cull_per_ray": cnt["cyl_calls"] / max(cnt["rays"], 1),
