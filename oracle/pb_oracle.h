@@ -6,11 +6,15 @@
  * (CastPhotonBeams -> BoundPhotonBeams -> BuildTree -> DrawStandard ->
  * PutPixelSDL) is checked against the reference's committed render
  * (screenshot.png/.bmp) in tests/test_oracle_golden.py, and ClosestIntersection,
- * HitBoundingBox, HitCylinder, findRotationMatrix, LoadTestModel and
+ * HitBoundingBox, HitCylinder, HitCone, findRotationMatrix, LoadTestModel and
  * CreateSurface are checked bit-for-bit against the reference's own functions
  * compiled from Source/Intersections.h, TestModelH.h and Tessendorf.h
- * (oracle/_ref).  Extinction3D / Integral_73Het (heterogeneous medium) have no
- * reference artefact and no SDL-free build: for them parity is UNPINNED.
+ * (oracle/_ref).  RunAnalysis (analysis_oracle.cpp) reproduces the reference's
+ * committed NSD.csv and the rRMSE.csv its own function writes, text for text.
+ * The functions whose headers need SDL have no reference artefact beyond the
+ * configuration-1 render: Extinction3D, Integral_73 / Integral_73Het,
+ * Integral_721_ada, the SHORT_VIEW draw order and RecastPhotonBeams (which does
+ * not terminate as written; see there) are restated only — parity UNPINNED.
  */
 #ifndef PB_ORACLE_H
 #define PB_ORACLE_H
