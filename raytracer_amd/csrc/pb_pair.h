@@ -413,7 +413,8 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
   const float dpy = __builtin_fmaf(f.Rinv[7], l.z, __builtin_fmaf(f.Rinv[4], l.y, f.Rinv[1] * l.x));
   const float y0 = __builtin_fmaf(t0, dpy, f.oy);
   const float y1 = __builtin_fmaf(t1, dpy, f.oy);
-  if (fmaxf(y0, y1) < 0.0f || fminf(y0, y1) > 1.0f) return 1;      // passes below or above both caps
+  const float y_low = fminf(y0, y1);
+  if (fmaxf(y0, y1) < 0.0f || y_low > 1.0f) return 1;               // passes below or above both caps
   const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);         // y of the entry and exit points
   const float sy = __builtin_amdgcn_fmed3f(y1, 0.0f, 1.0f);
   const float dt = t1 - t0;
@@ -433,14 +434,15 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
     if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) shortcut_wrong++;
   }
   const float chord = tc_plus - tc_minus;
-  const float tb_minus = __builtin_fmaf(fminf(fy, sy), f.len, f.tb0);
+  // tc- + tb- = len (th_first + min(fy, sy)) + tb0, and min(fy, sy) is the clamped min(y0, y1)
+  const float reach = __builtin_fmaf(thf + __builtin_amdgcn_fmed3f(y_low, 0.0f, 1.0f), f.len, f.tb0);
   const float cm1 = fabsf(dpy) - 1.0f;
   const float x = extinction * chord * cm1;
   float phi;                                                        // (exp(x) - 1) / x
   if (__builtin_expect(fabsf(x) < 0.02f, 1))
     phi = __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
   else phi = (__expf(x) - 1.0f) * fast_rcp(x);
-  const float fall = __expf(-extinction * (tc_minus + tb_minus));
+  const float fall = __builtin_amdgcn_exp2f(reach * (extinction * -1.44269504f));   // exp(-sigma_t (tc- + tb-))
   integral_out = (double)(chord * phi * fall);
   return 2;
 }
