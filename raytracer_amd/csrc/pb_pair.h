@@ -417,8 +417,7 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
   if (fmaxf(y0, y1) < 0.0f || y_low > 1.0f) return 1;               // passes below or above both caps
   const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);         // y of the entry and exit points
   const float sy = __builtin_amdgcn_fmed3f(y1, 0.0f, 1.0f);
-  const float dt = t1 - t0;
-  const float q = dt * fast_rcp(y0 - y1);                           // unused (selected away) where y0 == y1
+  const float q = -fast_rcp(dpy);                                   // (t1 - t0) / (y0 - y1); selected away where dpy == 0
   const float thf = (fy == y0) ? t0 : __builtin_fmaf(y0 - fy, q, t0);
   const float ths = (sy == y1) ? t1 : __builtin_fmaf(y0 - sy, q, t0);
   const float tc_minus = thf * f.len;
