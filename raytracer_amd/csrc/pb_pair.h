@@ -395,6 +395,12 @@ PB_DI int eval_pair_generic(const SegFrame& f, const HetFrame& hf, V3 seg_start,
 //    enters the cylinder in front of the surface, since it enters the box no later; otherwise, and for
 //    every other segment, the exact HitBoundingBox gate runs.
 PB_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// a * b with 0 * anything = 0 (also 0 * inf and 0 * NaN)
+PB_DI float mul_zero_wins(float a, float b) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 template <bool CHECK>
 PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong) {
@@ -418,8 +424,9 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
   const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);         // y of the entry and exit points
   const float sy = __builtin_amdgcn_fmed3f(y1, 0.0f, 1.0f);
   const float q = -fast_rcp(dpy);                                   // (t1 - t0) / (y0 - y1); selected away where dpy == 0
-  const float thf = (fy == y0) ? t0 : __builtin_fmaf(y0 - fy, q, t0);
-  const float ths = (sy == y1) ? t1 : __builtin_fmaf(y0 - sy, q, t0);
+  // t0 + (y0 - y) q, with a multiply for which 0 * inf = 0: where no cap is crossed the first factor is 0
+  const float thf = t0 + mul_zero_wins(y0 - fy, q);
+  const float ths = t1 + mul_zero_wins(y1 - sy, q);
   const float tc_minus = thf * f.len;
   const float tc_plus = ths * f.len;
   const bool sure = (f.qflags & 16u) && (tc_minus < r.maxd * 0.99999f);
