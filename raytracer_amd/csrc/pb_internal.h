@@ -41,7 +41,8 @@ struct __attribute__((aligned(64))) SegFrame {
   float tb0;       // 14      |start-orig_start|
   uint32_t qflags; // 15      bit i: origin inside slab i (MIDDLE); bit 3: origin inside the box;
                    //         bit 4: the gate box contains the segment's cylinder; bit 5: the record is a cone's
-                   //         (HitCone, Intersections.h:145-305): frame about orig_start, c4 = 4 c of :196-200
+                   //         (HitCone, Intersections.h:145-305): frame about orig_start, c4 = 4 c of :196-200;
+                   //         bit 6: the three weights W are equal
   double W[3];     // 16..21  energy*(1/(4 PI))*(sigma_s/(PI r^2)) (721) or energy*(1/(4 PI)) (73het)
   float lo[3];     // 22..24  gate box, min_b of HitBoundingBox
   float hi[3];     // 25..27  max_b

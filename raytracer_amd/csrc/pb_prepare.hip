@@ -167,6 +167,7 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
     }
     f.W[k] = w;
   }
+  if (f.W[0] == f.W[1] && f.W[1] == f.W[2]) f.qflags |= 64u;
   f.radius = s.radius;
   f.len = len;
   f.ymin = ymin;

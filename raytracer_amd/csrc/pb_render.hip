@@ -880,6 +880,7 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
     r.d1 = (MODE != PB_MODE_721) ? v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]) : r.dn;
     r.active = r.maxd >= 0.0f;
     unsigned long long ai[3] = {0ull, 0ull, 0ull};
+    unsigned long long ag = 0ull;      // contributions of segments whose three weights are equal
     uint32_t nc = 0;
     {
       const int cbase = 0, cn = n;             // n <= PB_SLICE, the capacity of surv
@@ -920,9 +921,14 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
             // the display range
             integral = fmin(integral, PB_FIX_LIMIT / fmax(f.W[0], fmax(f.W[1], f.W[2])));
           }
-          ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
-          ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[1], integral, PB_FIX_MAGIC));
-          ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[2], integral, PB_FIX_MAGIC));
+          if (f.qflags & 64u) {
+            // the three weights are equal (a beam that has not met a coloured wall): one sum serves all channels
+            ag += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
+          } else {
+            ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
+            ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[1], integral, PB_FIX_MAGIC));
+            ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[2], integral, PB_FIX_MAGIC));
+          }
           nc++;
         }
         if (COUNT) { c_cand += r.active ? 1 : 0; c_cyl += (res >= 1) ? 1 : 0; c_valid += (res == 2) ? 1 : 0; }
@@ -935,9 +941,9 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
       // (the adds run at the memory side in 64-byte requests; pixel-major rows cost three times as many)
       unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
       const unsigned long long bias = (unsigned long long)nc * magic_bits;
-      atomicAdd(&dst[0], ai[0] - bias);
-      atomicAdd(&dst[64], ai[1] - bias);
-      atomicAdd(&dst[128], ai[2] - bias);
+      atomicAdd(&dst[0], ai[0] + ag - bias);
+      atomicAdd(&dst[64], ai[1] + ag - bias);
+      atomicAdd(&dst[128], ai[2] + ag - bias);
     }
   }
   if (COUNT) {
