@@ -157,11 +157,14 @@ constexpr int PB_SLICE = 512;           // candidates of a macro list handed to 
 constexpr int PB_BIN_FAN = 8;            // lanes that share the macro rows of one segment in the binning passes
 constexpr int PB_BIN_SUBS = 1;          // sub-counters per tile in the binning passes (power of two)
 constexpr int PB_STACK_CAP = 2048;
-// Fixed-point radiance accumulation of the binned path: contributions are rounded to multiples of 2^-40
-// (9e-13) by adding PB_FIX_MAGIC = 1.5 * 2^12 in double, and summed as 64-bit integers, so the sum does
-// not depend on the order in which candidates are met.  Valid for |contribution| < 2048.
-#define PB_FIX_MAGIC 6144.0
-#define PB_FIX_SCALE 9.094947017729282e-13   /* 2^-40 */
+// Fixed-point radiance accumulation of the binned path: a contribution c >= 0 is scaled by 2^-10 and added to
+// PB_FIX_MAGIC = 4.0 in double, which rounds it to a multiple of ulp(4.0) = 2^-50 (2^-40 of c, 9e-13), and the
+// bit patterns are summed as 64-bit integers, so the sum does not depend on the order in which candidates
+// are met.  Valid for c < 4096.  (4.0 is an inline constant of the FP64 instructions; any other anchor costs
+// two register moves per contribution.)
+#define PB_FIX_MAGIC 4.0
+#define PB_FIX_PRESCALE 0.0009765625          /* 2^-10 */
+#define PB_FIX_SCALE 9.094947017729282e-13   /* 2^-40: one unit of the sums, in radiance */
 #define PB_FIX_LIMIT 2047.0                   /* larger contributions saturate here (display range is [0,1]) */
 
 enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, PB_CNT_NODES, PB_CNT_GATED, PB_CNT_SHORTCUT_WRONG,

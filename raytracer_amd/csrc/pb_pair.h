@@ -402,8 +402,10 @@ PB_DI float mul_zero_wins(float a, float b) {
   return r;
 }
 
+// log2_scale: the integral is returned times 2^log2_scale (folded into the exponential at no cost).
 template <bool CHECK>
-PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong) {
+PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong,
+                             float log2_scale = 0.0f) {
   const V3 l = r.l;
   const float dpx = __builtin_fmaf(f.Rinv[6], l.z, __builtin_fmaf(f.Rinv[3], l.y, f.Rinv[0] * l.x));
   const float dpz = __builtin_fmaf(f.Rinv[8], l.z, __builtin_fmaf(f.Rinv[5], l.y, f.Rinv[2] * l.x));
@@ -448,7 +450,7 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
   if (__builtin_expect(fabsf(x) < 0.02f, 1))
     phi = __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
   else phi = (__expf(x) - 1.0f) * fast_rcp(x);
-  const float fall = __builtin_amdgcn_exp2f(reach * (extinction * -1.44269504f));   // exp(-sigma_t (tc- + tb-))
+  const float fall = __builtin_amdgcn_exp2f(__builtin_fmaf(reach, extinction * -1.44269504f, log2_scale));   // exp(-sigma_t (tc- + tb-))
   integral_out = (double)(chord * phi * fall);
   return 2;
 }

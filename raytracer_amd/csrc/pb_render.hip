@@ -370,9 +370,11 @@ PB_DI SegFrame fetch_frame(const SegFrame* frames, int sidx) {
 }
 
 // Radiance weight times integral for one pair, by either estimator.
+// log2_scale: the fast estimator can return its integral times 2^log2_scale for free; FOLDED tells the caller
+// whether that happened.
 template <bool COUNT, bool PRECISE, int MODE>
 PB_DI int eval_pair(const RenderParams& p, int sidx, const SegFrame& f, const Ray& r, double& integral,
-                    unsigned long long& c_wrong) {
+                    unsigned long long& c_wrong, float log2_scale = 0.0f) {
   if (MODE == PB_MODE_73HET || MODE == PB_MODE_GENERIC) {
     const HetFrame hf = pb_uniform(p.het)[sidx];
     const PB_CONST_AS float* A = pb_uniform((const float*)p.capA) + 4 * (size_t)sidx;
@@ -386,7 +388,7 @@ PB_DI int eval_pair(const RenderParams& p, int sidx, const SegFrame& f, const Ra
                            integral);
   }
   return PRECISE ? eval_pair_721(f, r, p.extinction_c, integral)
-                 : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, integral, c_wrong);
+                 : eval_pair_721_fast<COUNT>(f, r, p.extinction_c, integral, c_wrong, log2_scale);
 }
 
 template <bool COUNT, bool PRECISE, int MODE>
@@ -914,13 +916,15 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
         const uint32_t next_idx = surv[(k + 1 < ns) ? k + 1 : k];   // read now, needed at the end of the iteration
         const SegFrame f = fetch_frame<PRECISE>(p.frames, sidx);
         double integral = 0.0;
-        const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong);
+        constexpr bool FOLDED = !PRECISE && MODE == PB_MODE_721;      // the 2^-10 of the fixed-point sums
+        const int res = eval_pair<COUNT, PRECISE, MODE>(p, sidx, f, r, integral, c_wrong, FOLDED ? -10.0f : 0.0f);
         if (res == 2) {
           if (MODE != PB_MODE_721) {
             // 1/sin(theta) is unbounded for a beam seen end-on, 1/r^2 at a cone's apex: saturate far above
             // the display range
             integral = fmin(integral, PB_FIX_LIMIT / fmax(f.W[0], fmax(f.W[1], f.W[2])));
           }
+          if (!FOLDED) integral = integral * PB_FIX_PRESCALE;
           if (f.qflags & 64u) {
             // the three weights are equal (a beam that has not met a coloured wall): one sum serves all channels
             ag += (unsigned long long)__double_as_longlong(__builtin_fma(f.W[0], integral, PB_FIX_MAGIC));
