@@ -271,7 +271,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.precise = ctx->precise ? 1 : 0;
   // a rank's share of interleaved strips has few items: shorter ones keep the longest wave short
   p.slice = ctx->tune_slice > 0 ? ctx->tune_slice : (strip_stride > 1 ? 96 : 128);   // render_binned refines it per frame geometry
-  p.eval_waves = ctx->tune_waves; p.ablate = ctx->tune_ablate;
+  p.eval_waves = ctx->tune_waves;
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
 
@@ -375,7 +375,6 @@ int pb_create(const pb_control* control, int device, pb_ctx** out) {
   if (rc_set_up != PB_OK) { pb_destroy(ctx); return rc_set_up; }      // releases whatever was created
   if (const char* e = std::getenv("PB_TUNE_SLICE")) { int v = std::atoi(e); if (v >= 32 && v <= PB_SLICE) ctx->tune_slice = v; }
   if (const char* e = std::getenv("PB_TUNE_WAVES")) { int v = std::atoi(e); if (v == 0 || (v >= 64 && v <= (1 << 20))) ctx->tune_waves = v; }
-  if (const char* e = std::getenv("PB_TUNE_ABLATE")) ctx->tune_ablate = std::atoi(e);
   *out = ctx;
   return PB_OK;
 }

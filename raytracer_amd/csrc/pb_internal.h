@@ -139,7 +139,6 @@ struct RenderParams {
   int n_items_host;         // number of items of this frame as measured when the workspace was sized
   int slice;                // candidates of a macro list per evaluation item (<= PB_SLICE)
   int eval_waves;           // size of the persistent evaluation grid
-  int ablate;               // tuning only (PB_TUNE_ABLATE): 1 skip the pixel atomics, 2 skip the pair loop, 4 skip refinement
   // LBVH (lbvh_n < 2: scan all segments)
   const LbvhNode* lbvh_nodes;
   const float4* lbvh_sA;    // capsules in Morton order
@@ -244,7 +243,6 @@ struct pb_ctx {
   unsigned long long* d_counters = nullptr;
   bool count_on = false;
   bool precise = false;
-  int tune_ablate = 0;
   int ws_slice = 0;                       // item length chosen for the frame geometry of ws_key (0: not chosen yet)
   int tune_slice = 0, tune_waves = 0;     // 0: defaults chosen per frame   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
   pb_stats stats;

@@ -889,7 +889,7 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
       // 1. lanes test the candidates against this tile's pyramid, REFINE_UNROLL x 64 at a time;
       //    survivors are compacted into LDS
       int ns = 0;
-      for (int base = 0; base < ((p.ablate & 4) ? 0 : cn); base += 64 * REFINE_UNROLL) {
+      for (int base = 0; base < cn; base += 64 * REFINE_UNROLL) {
         uint32_t cand[REFINE_UNROLL];
         float4 ca[REFINE_UNROLL], cb[REFINE_UNROLL];
 #pragma unroll
@@ -911,7 +911,6 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
       __syncthreads();
       // 2. every lane evaluates its own ray against each survivor (wave-uniform record, scalar loads)
       int sidx = ns > 0 ? __builtin_amdgcn_readfirstlane((int)surv[0]) : 0;
-      if (p.ablate & 2) ns = 0;
       for (int k = 0; k < ns; ++k) {
         const uint32_t next_idx = surv[(k + 1 < ns) ? k + 1 : k];   // read now, needed at the end of the iteration
         const SegFrame f = fetch_frame<PRECISE>(p.frames, sidx);
@@ -940,7 +939,7 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
       }
       __syncthreads();   // surv is rewritten by the next item
     }
-    if (nc && !(p.ablate & 1)) {
+    if (nc) {
       // sums are kept per tile, [tile][channel][lane]: one atomic instruction covers 512 contiguous bytes
       // (the adds run at the memory side in 64-byte requests; pixel-major rows cost three times as many)
       unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
