@@ -975,6 +975,113 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   eval_bins_body<false, false, PB_MODE_721>(p, surv);
 }
 
+// Integral_73Het / Integral_73 frames.  About one candidate-lane pair in four is a valid hit, and the integral
+// behind a hit is long (closest approach in double, a walk through the grid along the view ray), so evaluating
+// it inside the pair loop leaves most lanes idle.  Here the pair loop only runs HitCylinder and queues the valid
+// (ray, segment) pairs in LDS; whenever 64 are waiting every lane takes one, evaluates the integral and adds
+// the result to its ray's sums in LDS.  The sums are fixed point, so the order of the additions does not
+// matter and the frame equals eval_bins_kernel's bit for bit.
+constexpr int HIT_QUEUE = 128;
+__global__ __launch_bounds__(64) void eval_bins_het_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  __shared__ uint32_t q_seg[HIT_QUEUE], q_ray[HIT_QUEUE];
+  __shared__ float q_pt[6][HIT_QUEUE];             // entry and exit points of the hit
+  __shared__ float s_d1[3][64];                    // the rays' normalised directions
+  __shared__ unsigned long long s_acc[3][64];
+  const int lane = threadIdx.x;
+  const uint32_t produced = p.ctrl[0];
+  const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
+  const int nsub = p.ssaa * p.ssaa;
+  const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
+  GridView grid;
+  grid.z = p.grid_z; grid.side = p.grid_side;
+  for (uint32_t c = blockIdx.x; c < n_items; c += gridDim.x) {
+    const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
+    const int group = (int)it[0];
+    const uint32_t start = it[1];
+    const int cn = (int)it[2];
+    const int tile = group / nsub;
+    V3 pl[4];
+    tile_planes(p, tile % p.tiles_x, tile / p.tiles_x, pl);
+    const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+    Ray r;
+    r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+    r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
+    r.maxd = rr[6 * 64 + lane];
+    r.d1 = r.dn;
+    r.active = r.maxd >= 0.0f;
+    s_d1[0][lane] = rr[8 * 64 + lane]; s_d1[1][lane] = rr[9 * 64 + lane]; s_d1[2][lane] = rr[10 * 64 + lane];
+    s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull;
+    int ns = 0;
+    for (int base = 0; base < cn; base += 64) {
+      const int k = base + lane;
+      const uint32_t cand = (k < cn) ? p.bin_list[start + k] : 0xffffffffu;
+      bool touch = false;
+      if (cand != 0xffffffffu) touch = axis_touches_pyramid(p.capA[cand], p.capB[cand], pl);
+      const unsigned long long mask = __ballot(touch);
+      if (touch) surv[ns + (int)lanes_below(mask)] = cand;
+      ns += __builtin_popcountll(mask);
+    }
+    __syncthreads();
+    int pending = 0;
+    // the top `take` entries of the queue, one per lane
+    auto drain = [&](int take) {
+      __syncthreads();
+      if (lane < take) {
+        const int e = pending - take + lane;
+        const uint32_t sidx = q_seg[e], rl = q_ray[e];
+        CylHit h;
+        h.entry = v3(q_pt[0][e], q_pt[1][e], q_pt[2][e]);
+        h.exit = v3(q_pt[3][e], q_pt[4][e], q_pt[5][e]);
+        Ray rq;
+        rq.d1 = v3(s_d1[0][rl], s_d1[1][rl], s_d1[2][rl]);
+        const HetFrame hf = p.het[sidx];
+        const float4 A = p.capA[sidx], B = p.capB[sidx];
+        const double W0 = p.frames[sidx].W[0], W1 = p.frames[sidx].W[1], W2 = p.frames[sidx].W[2];
+        double integral = integral_73het(grid, v3(A.x, A.y, A.z), v3(B.x, B.y, B.z), hf, h, rq, p.extinction_c, p.scattering_c);
+        // 1/sin(theta) is unbounded for a beam seen end-on: saturate far above the display range
+        integral = fmin(integral, PB_FIX_LIMIT / fmax(W0, fmax(W1, W2)));
+        integral = integral * PB_FIX_PRESCALE;
+        const unsigned long long v0 = (unsigned long long)__double_as_longlong(__builtin_fma(W0, integral, PB_FIX_MAGIC)) - magic_bits;
+        const unsigned long long v1 = (unsigned long long)__double_as_longlong(__builtin_fma(W1, integral, PB_FIX_MAGIC)) - magic_bits;
+        const unsigned long long v2 = (unsigned long long)__double_as_longlong(__builtin_fma(W2, integral, PB_FIX_MAGIC)) - magic_bits;
+        if (v0) atomicAdd(&s_acc[0][rl], v0);
+        if (v1) atomicAdd(&s_acc[1][rl], v1);
+        if (v2) atomicAdd(&s_acc[2][rl], v2);
+      }
+      pending -= take;
+      __syncthreads();
+    };
+    int sidx = ns > 0 ? __builtin_amdgcn_readfirstlane((int)surv[0]) : 0;
+    for (int k = 0; k < ns; ++k) {
+      const uint32_t next_idx = surv[(k + 1 < ns) ? k + 1 : k];
+      const SegFrame f = fetch_frame<true>(p.frames, sidx);
+      CylHit h;
+      const bool valid = hit_cylinder_exact(f, r, h) == 2;
+      const unsigned long long mask = __ballot(valid);
+      if (valid) {
+        const int e = pending + (int)lanes_below(mask);
+        q_seg[e] = (uint32_t)sidx; q_ray[e] = (uint32_t)lane;
+        q_pt[0][e] = h.entry.x; q_pt[1][e] = h.entry.y; q_pt[2][e] = h.entry.z;
+        q_pt[3][e] = h.exit.x; q_pt[4][e] = h.exit.y; q_pt[5][e] = h.exit.z;
+      }
+      pending += __builtin_popcountll(mask);
+      if (pending >= 64) drain(64);
+      sidx = __builtin_amdgcn_readfirstlane((int)next_idx);
+    }
+    if (pending > 0) drain(pending);
+    __syncthreads();
+    const unsigned long long a0 = s_acc[0][lane], a1 = s_acc[1][lane], a2 = s_acc[2][lane];
+    if (a0 | a1 | a2) {
+      unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
+      atomicAdd(&dst[0], a0);
+      atomicAdd(&dst[64], a1);
+      atomicAdd(&dst[128], a2);
+    }
+    __syncthreads();   // surv, the queue and the sums are rewritten by the next item
+  }
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
   if (p.fused_queue && blockIdx.x == 0) {
     // the bin counters of the next frame start at zero (the queue and the lists have been consumed)
@@ -1107,7 +1214,7 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   }
   else if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
     if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(eval_bins_het_kernel, dim3(waves), dim3(64), 0, s, p);
   }
   else if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
