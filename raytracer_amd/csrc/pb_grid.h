@@ -75,10 +75,17 @@ struct DdaWalk {
       ext = sample(g, 0.0f, idx);
       return true;
     }
-    float t;
-    if ((tx < ty) && (tx < tz)) { t = tx; tx += delta.x; idx.x += (dir.x < 0) ? -1.0f : 1.0f; }
-    else if (ty < tz)           { t = ty; ty += delta.y; idx.y += (dir.y < 0) ? -1.0f : 1.0f; }
-    else                        { t = tz; tz += delta.z; idx.z += (dir.z < 0) ? -1.0f : 1.0f; }
+    // selects, not branches: with branches the compiler indexes idx as an array and puts it in scratch memory
+    const bool step_x = (tx < ty) && (tx < tz);
+    const bool step_y = !step_x && (ty < tz);
+    const bool step_z = !step_x && !step_y;
+    const float t = step_x ? tx : (step_y ? ty : tz);
+    tx = step_x ? tx + delta.x : tx;
+    ty = step_y ? ty + delta.y : ty;
+    tz = step_z ? tz + delta.z : tz;
+    idx.x = step_x ? idx.x + ((dir.x < 0) ? -1.0f : 1.0f) : idx.x;
+    idx.y = step_y ? idx.y + ((dir.y < 0) ? -1.0f : 1.0f) : idx.y;
+    idx.z = step_z ? idx.z + ((dir.z < 0) ? -1.0f : 1.0f) : idx.z;
     // a NaN direction (zero-length ray) never satisfies t > t_max: the guard ends such a walk
     if (t > t_max || idx.x < 0 || idx.y < 0 || idx.x > res_x || idx.y > res_y || ++guard > 4096) {
       state = 2;
