@@ -66,20 +66,14 @@ struct DdaWalk {
     return ext;
   }
 
-  // Next (distance, extinction) sample; false once the list is exhausted.  Heterogeneous.h:84-122
-  PB_DI bool next(const GridView& g, float& dist, float& ext) {
-    if (state == 2) return false;
-    if (state == 0) {
-      state = 1;
-      dist = 0.0f;
-      ext = sample(g, 0.0f, idx);
-      return true;
-    }
+  // One step of the walk (Heterogeneous.h:84-122): true when it leaves the grid or passes t_max, and the
+  // closing sample (t_max, previous cell) is due; otherwise the crossing distance is in t and idx has moved.
+  PB_DI bool advance(float& t) {
     // selects, not branches: with branches the compiler indexes idx as an array and puts it in scratch memory
     const bool step_x = (tx < ty) && (tx < tz);
     const bool step_y = !step_x && (ty < tz);
     const bool step_z = !step_x && !step_y;
-    const float t = step_x ? tx : (step_y ? ty : tz);
+    t = step_x ? tx : (step_y ? ty : tz);
     tx = step_x ? tx + delta.x : tx;
     ty = step_y ? ty + delta.y : ty;
     tz = step_z ? tz + delta.z : tz;
@@ -87,15 +81,19 @@ struct DdaWalk {
     idx.y = step_y ? idx.y + ((dir.y < 0) ? -1.0f : 1.0f) : idx.y;
     idx.z = step_z ? idx.z + ((dir.z < 0) ? -1.0f : 1.0f) : idx.z;
     // a NaN direction (zero-length ray) never satisfies t > t_max: the guard ends such a walk
-    if (t > t_max || idx.x < 0 || idx.y < 0 || idx.x > res_x || idx.y > res_y || ++guard > 4096) {
-      state = 2;
-      dist = t_max;
-      ext = sample(g, t_max, prev);
-      return true;
-    }
-    prev = idx;
+    return t > t_max || idx.x < 0 || idx.y < 0 || idx.x > res_x || idx.y > res_y || ++guard > 4096;
+  }
+
+  // Next (distance, extinction) sample; false once the list is exhausted.
+  PB_DI bool next(const GridView& g, float& dist, float& ext) {
+    if (state == 2) return false;
+    float t = 0.0f;
+    V3 at = idx;
+    if (state == 0) state = 1;
+    else if (advance(t)) { state = 2; t = t_max; at = prev; }
+    else { prev = idx; at = idx; }
     dist = t;
-    ext = sample(g, t, idx);
+    ext = sample(g, t, at);
     return true;
   }
 };
@@ -104,9 +102,17 @@ struct DdaWalk {
 PB_DI float extinction3d_mean(const GridView& g, V3 start, V3 end) {
   DdaWalk w;
   w.begin(g, start, end);
-  float sum = 0.0f, d, e;
-  int n = 0;
-  while (w.next(g, d, e)) { sum += e; n++; }
+  float sum = w.sample(g, 0.0f, w.idx);
+  int n = 1;
+  for (;;) {
+    float t;
+    const bool done = w.advance(t);
+    const V3 at = done ? w.prev : w.idx;
+    sum += w.sample(g, done ? w.t_max : t, at);
+    n++;
+    if (done) break;
+    w.prev = w.idx;
+  }
   return sum / (float)n;
 }
 
