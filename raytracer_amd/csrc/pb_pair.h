@@ -186,16 +186,20 @@ PB_DI int hit_cylinder_exact(const SegFrame& f, const Ray& r, CylHit& h) {
 
 // Integral_721 (BeamRadiance.h:86-110) on a valid hit: float products and float exp, widened for the
 // quotient.  Same return convention as hit_cylinder_exact.
-PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, double& integral_out) {
-  CylHit h;
-  const int res = hit_cylinder_exact(f, r, h);
-  if (res != 2) return res;
+PB_DI double integral_721(const SegFrame& f, const CylHit& h, const Ray& r, float extinction) {
   const V3 l = r.l;
   const float cos_theta = f.bdir[0] * (-l.x) + f.bdir[1] * (-l.y) + f.bdir[2] * (-l.z);
   const float cm1 = fabsf(cos_theta) - 1;
   const float num = expf(-extinction * (h.tc_minus - h.tc_plus) * cm1) - 1;
   const float den = expf(extinction * (h.tc_minus + h.tb_minus)) * extinction * cm1;
-  integral_out = (double)num / (double)den;
+  return (double)num / (double)den;
+}
+
+PB_DI int eval_pair_721(const SegFrame& f, const Ray& r, float extinction, double& integral_out) {
+  CylHit h;
+  const int res = hit_cylinder_exact(f, r, h);
+  if (res != 2) return res;
+  integral_out = integral_721(f, h, r, extinction);
   return 2;
 }
 

@@ -975,18 +975,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   eval_bins_body<false, false, PB_MODE_721>(p, surv);
 }
 
-// Integral_73Het / Integral_73 frames.  About one candidate-lane pair in four is a valid hit, and the integral
-// behind a hit is long (closest approach in double, a walk through the grid along the view ray), so evaluating
-// it inside the pair loop leaves most lanes idle.  Here the pair loop only runs HitCylinder and queues the valid
-// (ray, segment) pairs in LDS; whenever 64 are waiting every lane takes one, evaluates the integral and adds
-// the result to its ray's sums in LDS.  The sums are fixed point, so the order of the additions does not
-// matter and the frame equals eval_bins_kernel's bit for bit.
+// Frames of the estimators whose integral is long: Integral_73Het / Integral_73 (closest approach in double, a
+// walk through the grid along the view ray) and BeamRadiance's dispatch (Integral_721_ada's Riemann sum).  About
+// one candidate-lane pair in four is a valid hit, so evaluating the integral inside the pair loop leaves most
+// lanes idle.  Here the pair loop only runs HitCylinder / HitCone and queues the valid (ray, segment) pairs in
+// LDS; whenever 64 are waiting every lane takes one, evaluates the integral and adds the result to its ray's
+// sums in LDS.  The sums are fixed point, so the order of the additions does not matter and the frame equals
+// eval_bins_kernel's bit for bit.
 constexpr int HIT_QUEUE = 128;
-__global__ __launch_bounds__(64) void eval_bins_het_kernel(const RenderParams p) {
+template <int MODE>
+__global__ __launch_bounds__(64) void eval_bins_queue_kernel(const RenderParams p) {
+  constexpr bool GENERIC = MODE == PB_MODE_GENERIC;
+  constexpr int HIT_WORDS = GENERIC ? 9 : 6;       // entry and exit points; tc-, tc+, tb- for Integral_721(_ada)
   __shared__ uint32_t surv[PB_SLICE];
   __shared__ uint32_t q_seg[HIT_QUEUE], q_ray[HIT_QUEUE];
-  __shared__ float q_pt[6][HIT_QUEUE];             // entry and exit points of the hit
-  __shared__ float s_d1[3][64];                    // the rays' normalised directions
+  __shared__ float q_hit[HIT_WORDS][HIT_QUEUE];
+  __shared__ float s_ray[GENERIC ? 6 : 3][64];     // the rays' normalised directions (and l, for the 721 integrals)
   __shared__ unsigned long long s_acc[3][64];
   const int lane = threadIdx.x;
   const uint32_t produced = p.ctrl[0];
@@ -1010,7 +1014,8 @@ __global__ __launch_bounds__(64) void eval_bins_het_kernel(const RenderParams p)
     r.maxd = rr[6 * 64 + lane];
     r.d1 = r.dn;
     r.active = r.maxd >= 0.0f;
-    s_d1[0][lane] = rr[8 * 64 + lane]; s_d1[1][lane] = rr[9 * 64 + lane]; s_d1[2][lane] = rr[10 * 64 + lane];
+    s_ray[0][lane] = rr[8 * 64 + lane]; s_ray[1][lane] = rr[9 * 64 + lane]; s_ray[2][lane] = rr[10 * 64 + lane];
+    if (GENERIC) { s_ray[3][lane] = r.l.x; s_ray[4][lane] = r.l.y; s_ray[5][lane] = r.l.z; }
     s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull;
     int ns = 0;
     for (int base = 0; base < cn; base += 64) {
@@ -1027,19 +1032,38 @@ __global__ __launch_bounds__(64) void eval_bins_het_kernel(const RenderParams p)
     // the top `take` entries of the queue, one per lane
     auto drain = [&](int take) {
       __syncthreads();
-      if (lane < take) {
+      const bool mine = lane < take;
+      uint32_t rl = 0;
+      double W0 = 0.0, W1 = 0.0, W2 = 0.0, integral = 0.0;
+      if (mine) {
         const int e = pending - take + lane;
-        const uint32_t sidx = q_seg[e], rl = q_ray[e];
+        const uint32_t sidx = q_seg[e];
+        rl = q_ray[e];
         CylHit h;
-        h.entry = v3(q_pt[0][e], q_pt[1][e], q_pt[2][e]);
-        h.exit = v3(q_pt[3][e], q_pt[4][e], q_pt[5][e]);
+        h.entry = v3(q_hit[0][e], q_hit[1][e], q_hit[2][e]);
+        h.exit = v3(q_hit[3][e], q_hit[4][e], q_hit[5][e]);
         Ray rq;
-        rq.d1 = v3(s_d1[0][rl], s_d1[1][rl], s_d1[2][rl]);
-        const HetFrame hf = p.het[sidx];
-        const float4 A = p.capA[sidx], B = p.capB[sidx];
-        const double W0 = p.frames[sidx].W[0], W1 = p.frames[sidx].W[1], W2 = p.frames[sidx].W[2];
-        double integral = integral_73het(grid, v3(A.x, A.y, A.z), v3(B.x, B.y, B.z), hf, h, rq, p.extinction_c, p.scattering_c);
-        // 1/sin(theta) is unbounded for a beam seen end-on: saturate far above the display range
+        rq.d1 = v3(s_ray[0][rl], s_ray[1][rl], s_ray[2][rl]);
+        const SegFrame& f = p.frames[sidx];           // per-lane record: only the fields used below are loaded
+        W0 = f.W[0]; W1 = f.W[1]; W2 = f.W[2];
+        bool long_form = true;                        // Integral_73 / Integral_73Het
+        if (GENERIC) {
+          h.tc_minus = q_hit[6][e]; h.tc_plus = q_hit[7][e]; h.tb_minus = q_hit[8][e];
+          rq.l = v3(s_ray[3][rl], s_ray[4][rl], s_ray[5][rl]);
+          const bool cone = (f.qflags & 32u) != 0u;
+          long_form = !cone && p.one_dimensional != 0;
+          if (cone) integral = integral_721_ada(f, h, rq, p.extinction_c, p.scattering_c);
+          else if (!long_form) integral = integral_721(f, h, rq, p.extinction_c);
+        }
+        if (long_form) {
+          const HetFrame hf = p.het[sidx];
+          const float4 A = p.capA[sidx], B = p.capB[sidx];
+          integral = integral_73het(grid, v3(A.x, A.y, A.z), v3(B.x, B.y, B.z), hf, h, rq, p.extinction_c, p.scattering_c);
+        }
+      }
+      if (mine) {
+        // 1/sin(theta) is unbounded for a beam seen end-on, 1/r^2 at a cone's apex: saturate far above the
+        // display range
         integral = fmin(integral, PB_FIX_LIMIT / fmax(W0, fmax(W1, W2)));
         integral = integral * PB_FIX_PRESCALE;
         const unsigned long long v0 = (unsigned long long)__double_as_longlong(__builtin_fma(W0, integral, PB_FIX_MAGIC)) - magic_bits;
@@ -1057,13 +1081,20 @@ __global__ __launch_bounds__(64) void eval_bins_het_kernel(const RenderParams p)
       const uint32_t next_idx = surv[(k + 1 < ns) ? k + 1 : k];
       const SegFrame f = fetch_frame<true>(p.frames, sidx);
       CylHit h;
-      const bool valid = hit_cylinder_exact(f, r, h) == 2;
+      bool valid;
+      if (GENERIC && (f.qflags & 32u)) {
+        const HetFrame hf = pb_uniform(p.het)[sidx];
+        ConeFrame cf;
+        __builtin_memcpy(&cf, &hf, sizeof(cf));
+        valid = hit_cone_exact(f, cf, r, h) == 2;
+      } else valid = hit_cylinder_exact(f, r, h) == 2;
       const unsigned long long mask = __ballot(valid);
       if (valid) {
         const int e = pending + (int)lanes_below(mask);
         q_seg[e] = (uint32_t)sidx; q_ray[e] = (uint32_t)lane;
-        q_pt[0][e] = h.entry.x; q_pt[1][e] = h.entry.y; q_pt[2][e] = h.entry.z;
-        q_pt[3][e] = h.exit.x; q_pt[4][e] = h.exit.y; q_pt[5][e] = h.exit.z;
+        q_hit[0][e] = h.entry.x; q_hit[1][e] = h.entry.y; q_hit[2][e] = h.entry.z;
+        q_hit[3][e] = h.exit.x; q_hit[4][e] = h.exit.y; q_hit[5][e] = h.exit.z;
+        if (GENERIC) { q_hit[6][e] = h.tc_minus; q_hit[7][e] = h.tc_plus; q_hit[8][e] = h.tb_minus; }
       }
       pending += __builtin_popcountll(mask);
       if (pending >= 64) drain(64);
@@ -1210,11 +1241,11 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   if (waves < 1) waves = 1;
   if (mode == PB_MODE_GENERIC) {
     if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_GENERIC>), dim3(waves), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_GENERIC>), dim3(waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(eval_bins_queue_kernel<PB_MODE_GENERIC>, dim3(waves), dim3(64), 0, s, p);
   }
   else if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
     if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(eval_bins_het_kernel, dim3(waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(eval_bins_queue_kernel<PB_MODE_73HET>, dim3(waves), dim3(64), 0, s, p);
   }
   else if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
