@@ -162,6 +162,9 @@ def main():
 
     # ---- beam set: emitted once on rank 0 (GPU photon pass), broadcast, resident everywhere ----
     if rank == 0:
+        ctx.cast_photon_beams()
+        ctx.build_tree()
+        # again, with the buffers of the first pass in place: phases_ms is the warm photon pass (same seed, same beams)
         n_beams, n_segs = ctx.cast_photon_beams()
         segs = ctx.download_segments()
         root = np.concatenate(ctx.root_box()).astype(np.float32)
