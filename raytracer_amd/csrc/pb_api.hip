@@ -168,6 +168,17 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
     p.bin_list = ctx->d_bin_list; p.items = ctx->d_items; p.accum = ctx->d_accum;
     p.bin_capacity = ctx->ws_bin_cap; p.item_capacity = ctx->ws_item_cap;
     p.fused_queue = (mtiles <= pb_fused_queue_macros()) ? 1 : 0;
+    p.bin_mask = nullptr;
+    if (p.fused_queue && p.n_seg > 0) {
+      const size_t need = (size_t)p.n_seg * PB_BIN_FAN;
+      if (need > ctx->ws_mask_cap) {
+        if (ctx->d_bin_mask) PB_HIP(hipFree(ctx->d_bin_mask));
+        ctx->d_bin_mask = nullptr; ctx->ws_mask_cap = 0;
+        PB_HIP(hipMalloc(&ctx->d_bin_mask, sizeof(unsigned long long) * need));
+        ctx->ws_mask_cap = need;
+      }
+      p.bin_mask = ctx->d_bin_mask;
+    }
     PB_HIP(hipEventRecord(ctx->ev[0], s));
     if (p.fused_queue && !ctx->bins_clean)
       PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ctx->ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
@@ -386,7 +397,7 @@ void pb_destroy(pb_ctx* ctx) {
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
                   ctx->d_het, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
                   ctx->d_emit_tmp[1], ctx->d_rays, ctx->d_group_last,
-                  ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->d_tile_u32, ctx->d_bin_list, ctx->d_items, ctx->d_accum,
+                  ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->d_tile_u32, ctx->d_bin_list, ctx->d_bin_mask, ctx->d_items, ctx->d_accum,
                   ctx->d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
                   ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};
   for (void* p : ptrs) if (p) (void)hipFree(p);

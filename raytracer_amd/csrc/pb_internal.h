@@ -128,6 +128,7 @@ struct RenderParams {
   uint32_t* sub_fill;       // [macro tiles][PB_BIN_SUBS] fill cursors of the second binning pass
   uint32_t* sub_off;        // [macro tiles][PB_BIN_SUBS] start of each sub-list in bin_list (a macro tile's are adjacent)
   uint32_t* bin_list;       // [bin_capacity] segment indices, grouped by tile
+  unsigned long long* bin_mask;   // [n_seg][PB_BIN_FAN] what the counting pass found (bit 63: valid), or null
   uint32_t* items;          // [items][4]: group, start, n, 0
   uint32_t* item_off;       // [queue slots] first item of the tile in that slot (macro tiles in rank order)
   uint32_t* macro_cnt;      // [macro tiles] list length
@@ -232,6 +233,8 @@ struct pb_ctx {
   int ws_groups = 0, ws_chunks = 0;
   uint32_t* d_tile_u32 = nullptr;      // tile_count | item_off | macro_cnt | macro_rank (ws_tiles each) | sub_count | sub_fill | sub_off
   uint32_t* d_bin_list = nullptr;
+  unsigned long long* d_bin_mask = nullptr;   // the counting pass's findings per (segment, lane), for the filling pass
+  size_t ws_mask_cap = 0;
   uint32_t* d_items = nullptr;
   unsigned long long* d_accum = nullptr;
   uint32_t* d_scan_tmp = nullptr;

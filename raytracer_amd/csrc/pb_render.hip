@@ -629,6 +629,42 @@ PB_DI void for_each_macro_tile(const RenderParams& p, const float4 A4, const flo
   }
 }
 
+// The same visit, with what it found recorded: bit i of `mask` is the i-th (row, column) pair of this lane's
+// share of the rectangle, row by row.  Returns false (mask unusable) when the share has more than 63 pairs.
+template <class F>
+PB_DI bool for_each_macro_tile_masked(const RenderParams& p, const float4 A4, const float4 B4, int k, int mtx, int mty,
+                                      unsigned long long& mask, F&& hit) {
+  const float pad = A4.w * 1.001f + 1e-5f;
+  const TileRect rc = macro_rect(p, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), pad, mtx, mty);
+  const int ncols = rc.x1 - rc.x0 + 1;
+  const int nrows = (rc.y1 - (rc.y0 + k)) / PB_BIN_FAN + 1;
+  mask = 0ull;
+  const bool fits = ncols > 0 && (rc.y0 + k > rc.y1 || nrows * ncols <= 63);
+  for_each_macro_tile(p, A4, B4, k, mtx, mty, [&](int m) {
+    if (fits) {
+      const int my = m / mtx, mx = m % mtx;
+      mask |= 1ull << (((my - rc.y0 - k) / PB_BIN_FAN) * ncols + (mx - rc.x0));
+    }
+    hit(m);
+  });
+  return fits || ncols <= 0;
+}
+
+// Replays a recorded visit without clipping anything.
+template <class F>
+PB_DI void replay_macro_tiles(const RenderParams& p, const float4 A4, const float4 B4, int k, int mtx, int mty,
+                              unsigned long long mask, F&& hit) {
+  if (!mask) return;
+  const float pad = A4.w * 1.001f + 1e-5f;
+  const TileRect rc = macro_rect(p, v3(A4.x, A4.y, A4.z), v3(B4.x, B4.y, B4.z), pad, mtx, mty);
+  const int ncols = rc.x1 - rc.x0 + 1;
+  while (mask) {
+    const int i = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    hit((rc.y0 + k + (i / ncols) * PB_BIN_FAN) * mtx + rc.x0 + i % ncols);
+  }
+}
+
 // Binning passes.  A block takes 128 segments, PB_BIN_FAN lanes each (a long beam crosses the whole
 // image; one lane per segment walked up to 64 macro tiles one after the other).  Hits are first counted
 // per macro tile in LDS, so that a block issues one global atomic per macro tile it touches instead of
@@ -660,7 +696,20 @@ PB_DI void bin_body(const RenderParams& p, int n_macro, uint32_t* bin_lds, int b
   }
   for (int m = threadIdx.x; m < n_macro; m += BIN_THREADS) lcount[m] = 0u;
   __syncthreads();
-  if (live) for_each_macro_tile(p, A4, B4, k, mtx, mty, [&](int m) { atomicAdd(&lcount[m], 1u); });
+  // The walk over the macro tiles is done once per frame where possible: the counting pass records what it
+  // found per (segment, lane) and the filling pass replays that, twice (block-local counts, then placement).
+  constexpr unsigned long long MASK_VALID = 1ull << 63;
+  unsigned long long visited = 0ull;
+  bool recorded = false;
+  auto count_local = [&](int m) { atomicAdd(&lcount[m], 1u); };
+  if (live && FILL && p.bin_mask && (p.bin_mask[g] & MASK_VALID)) {
+    visited = p.bin_mask[g] & ~MASK_VALID;
+    recorded = true;
+    replay_macro_tiles(p, A4, B4, k, mtx, mty, visited, count_local);
+  } else if (live) {
+    recorded = for_each_macro_tile_masked(p, A4, B4, k, mtx, mty, visited, count_local);
+    if (!FILL && p.bin_mask) p.bin_mask[g] = recorded ? (visited | MASK_VALID) : 0ull;
+  }
   __syncthreads();
   for (int m = threadIdx.x; m < n_macro; m += BIN_THREADS) {
     const uint32_t c = lcount[m];
@@ -672,10 +721,12 @@ PB_DI void bin_body(const RenderParams& p, int n_macro, uint32_t* bin_lds, int b
   }
   if (!FILL) return;
   __syncthreads();
-  if (live) for_each_macro_tile(p, A4, B4, k, mtx, mty, [&](int m) {
+  auto place = [&](int m) {
     const uint32_t at = lbase[m] + atomicAdd(&lcount[m], 1u);
     if (at < (uint32_t)p.bin_capacity) p.bin_list[at] = (uint32_t)s;
-  });
+  };
+  if (live && recorded) replay_macro_tiles(p, A4, B4, k, mtx, mty, visited, place);    // the first walk's findings
+  else if (live) for_each_macro_tile(p, A4, B4, k, mtx, mty, place);
 }
 
 template <bool FILL, bool LDS>
