@@ -209,9 +209,15 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
       // lists amortise the per-item work better with longer ones.  Measured: 1052 segments 0.145 -> 0.100 ms at
       // 48 instead of 192, 17 424 segments best at 128.
       const uint32_t mean_list = need_bins / (uint32_t)(mtiles > 0 ? mtiles : 1);
-      int want = (int)(mean_list / 6 + 15) / 16 * 16;
-      const int longest = p.strip_stride >= 8 ? 48 : (p.strip_stride > 1 ? 96 : 128);   // a rank's share of strips has few items
-      want = want < 48 ? 48 : (want > longest ? longest : want);
+      // The estimators that queue their hits (Integral_73Het, the generic dispatch) spend 14 times as long per
+      // candidate and drain a partly filled queue at the end of every item: they want longer items (cfg3:
+      // 3.37 ms at 48, 3.08 at 96, 2.98 at 128..192, 3.11 at 256; its mean list is about 300).
+      const bool queued = mode != PB_MODE_721;
+      int want = (int)(mean_list / (queued ? 2 : 6) + 15) / 16 * 16;
+      int longest = p.strip_stride >= 8 ? 48 : (p.strip_stride > 1 ? 96 : 128);   // a rank's share of strips has few items
+      if (queued) longest = longest * 3 / 2;
+      const int shortest = queued ? 64 : 48;
+      want = want < shortest ? shortest : (want > longest ? longest : want);
       ctx->ws_slice = want;
       if (want != p.slice) {                 // same capacities, queue rebuilt with the new length
         p.slice = want;

@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // eval_bins_kernel's bit for bit.
 constexpr int HIT_QUEUE = 128;
 template <int MODE>
-__global__ __launch_bounds__(64) void eval_bins_queue_kernel(const RenderParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void eval_bins_queue_kernel(const RenderParams p) {
   constexpr bool GENERIC = MODE == PB_MODE_GENERIC;
   constexpr int HIT_WORDS = GENERIC ? 9 : 6;       // entry and exit points; tc-, tc+, tb- for Integral_721(_ada)
   __shared__ uint32_t surv[PB_SLICE];
