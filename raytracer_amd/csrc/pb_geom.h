@@ -8,12 +8,15 @@
 // its vertices, widened by 1e-3.  A ray outside them cannot satisfy the barycentric tests (they hold to a
 // few 1e-6), so the triangle is skipped without evaluating it; the result is unchanged.
 PB_DI bool closest_intersection(const TriPrep* __restrict__ tris, int n_tri, V4 start, V4 dir, V4& position,
-                                float& distance, int& index, const float4* __restrict__ screen_box = nullptr) {
+                                float& distance, int& index, const float4* __restrict__ screen_box = nullptr,
+                                unsigned long long only = ~0ull) {
   bool found = false;
   float best = 3.402823466e+38f;   // Intersections.h:57
   int best_i = -1;
   const float ndx = -dir.x, ndy = -dir.y, ndz = -dir.z;
   for (int i = 0; i < n_tri; ++i) {
+    // `only` (same for the whole wave): triangles 0..63 the caller has ruled out for all of its rays
+    if (i < 64 && !((only >> i) & 1ull)) continue;
     if (screen_box) {
       const float4 sb = screen_box[i];
       if (dir.x < sb.x * dir.z || dir.x > sb.y * dir.z || dir.y < sb.z * dir.z || dir.y > sb.w * dir.z) continue;

@@ -78,7 +78,8 @@ PB_DI int box_gate_quick(const float lo[3], const float hi[3], const float cand[
 }
 
 // Per-pixel set-up of DrawStandard, skeleton.cpp:342-350, then the root gate.
-PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
+// tri_mask (wave-uniform): triangles that can be hit by any ray of the wave, see closest_intersection.
+PB_DI Ray make_ray(const RenderParams& p, int sx, int sy, unsigned long long tri_mask = ~0ull) {
   Ray r;
   const float x_dir = sx - ((p.width * p.ssaa) / (float)2);
   const float y_dir = sy - ((p.height * p.ssaa) / (float)2);
@@ -86,7 +87,7 @@ PB_DI Ray make_ray(const RenderParams& p, int sx, int sy) {
   const V4 start = v4(0, 0, 0, 1);
   V4 pos = v4(0, 0, 0, 0);
   float dist; int idx;
-  r.active = closest_intersection(p.tris, p.n_tri, start, dir, pos, dist, idx, p.tri_box);
+  r.active = closest_intersection(p.tris, p.n_tri, start, dir, pos, dist, idx, p.tri_box, tri_mask);
   r.maxd = r.active ? length4(pos - start) : -1.0f;
   if (p.short_view && r.active) {
     // SHORT_VIEW (skeleton.cpp:442-449): the view ray ends at a free-flight distance drawn for it; the draw

@@ -501,7 +501,23 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane) {
       a[0] = 0ull; a[64] = 0ull; a[128] = 0ull;
     }
   }
-  Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj);
+  // Triangles whose screen box misses the whole tile are ruled out once per wave (lane i looks at triangle i)
+  // instead of once per ray; the per-ray box test and the exact intersection see the rest unchanged.
+  unsigned long long tri_mask = ~0ull;
+  {
+    const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
+    const float x_lo = (float)((p.x0 + 8 * tx) * p.ssaa + si) - half_w, x_hi = x_lo + (float)(7 * p.ssaa);
+    const float y_lo = (float)((p.y0 + 8 * tk * p.strip_stride) * p.ssaa + sj) - half_h, y_hi = y_lo + (float)(7 * p.ssaa);
+    bool may = true;
+    if (lane < p.n_tri) {
+      const float4 sb = p.tri_box[lane];
+      const float m = 1e-4f * p.focal;           // the screen boxes are in units of x / z, the rays' z is focal
+      may = !(x_hi < sb.x * p.focal - m * (1.0f + fabsf(sb.x)) || x_lo > sb.y * p.focal + m * (1.0f + fabsf(sb.y)) ||
+              y_hi < sb.z * p.focal - m * (1.0f + fabsf(sb.z)) || y_lo > sb.w * p.focal + m * (1.0f + fabsf(sb.w)));
+    }
+    tri_mask = __ballot(may);
+  }
+  Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj, tri_mask);
   r.active = r.active && in_image;
   const bool hit_scene = r.active;
   r.active = r.active && box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd);
