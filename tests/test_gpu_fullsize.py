@@ -91,3 +91,33 @@ def test_full_size_heterogeneous_properties(pb):
     small = ref < 1000.0
     err = np.abs(got - ref)[small]
     assert (err <= 1e-5 * np.maximum(1.0, np.abs(ref[small]))).all(), err.max()
+
+
+def test_largest_configuration_band(pb):
+    """4096^2, 1 000 000 photons, BOUNCES 3, heterogeneous medium (about 2.4e7 segments): one 128-row band through
+    the cone.  The band must not depend on how the frame is cut (two 64-row halves reassemble it bit for bit) and a
+    lattice of its pixels must match the oracle's flat scan over the same segments."""
+    S, band, y0 = 4096, 128, 1984
+    kw = dict(screen_width=S, screen_height=S, photon_number=1000000, bounces=3, heterogeneous=1, one_dimensional=1)
+    sigma, side = pb.make_grid()
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.set_grid(sigma, side)
+        n_beams, n_segs = ctx.cast_photon_beams()
+        whole = ctx.draw(0, y0, S, band, mode=pb.MODE_73HET, cull="bins")
+        halves = [ctx.draw(0, y0 + i * 64, S, 64, mode=pb.MODE_73HET, cull="bins") for i in range(2)]
+        segs = ctx.download_segments()
+        lo, hi = ctx.root_box()
+    assert n_beams > 1200000 and n_segs > 20000000 and len(segs) == n_segs
+    assert np.isfinite(whole).all() and whole.max() > 100.0 and (whole > 0).mean() > 0.9
+    assert np.array_equal(np.concatenate(halves, axis=0), whole)
+    tri, _ = orc.load_test_model()
+    for x in (1000, 2500):                                # the oracle threads over rows: one column per call
+        ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
+                                       segs, lo, hi, x, y0 + 4, 1, 16, step_x=1, step_y=8, mode=orc.MODE_73HET,
+                                       grid_sigma=sigma, side=side)
+        got = whole[4::8, x][:16].astype(np.float64)
+        small = ref[:, 0] < 1000.0                        # below the fixed-point saturation of single contributions
+        assert small.mean() > 0.8 and cnt["valid_hits"] > 1000
+        err = np.abs(got - ref[:, 0])[small]
+        assert (err <= 1e-5 * np.maximum(1.0, np.abs(ref[:, 0][small]))).all(), err.max()
