@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <mutex>
+#include <map>
 
 #include "pb_internal.h"
 #include "pb_scan.h"
@@ -273,7 +275,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.scattering_c = ctx->ctl.scattering_c;
   // Integral_73 reads the grid when HETEROGENEOUS is set (BeamRadiance.h:159-188)
   const bool generic_het = mode == PB_MODE_GENERIC && ctx->ctl.one_dimensional && ctx->ctl.heterogeneous;
-  p.het = ctx->d_het; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side;
+  p.het = ctx->d_het; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side; p.grid_fast_div = ctx->grid_fast_div;
   p.one_dimensional = ctx->ctl.one_dimensional;
   p.short_view = ctx->ctl.short_view; p.view_seed = ctx->ctl.seed;
   if (generic_het && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_GENERIC with one_dimensional and heterogeneous set needs pb_set_grid"); return PB_ERR_STATE; }
@@ -443,16 +445,55 @@ int pb_set_scene(pb_ctx* ctx, const float* tri_xyz, int n_tri, const float matri
   return PB_OK;
 }
 
+// DdaWalk::sample divides by the cell size c = 2 / (side - 1) twice per sample.  With r = RN(1 / c) the
+// sequence q = RN(x r), q' = RN(q + RN(x - q c) r) (both RN(.) of the second step are fused multiply-adds, the
+// inner one exact) gives the correctly rounded x / c for all x of a divisor, or fails for a few x, depending on
+// c; scaling x by a power of two scales every step exactly, so trying the 2^23 significands of one binade
+// settles it for every x whose intermediate results stay normal.  True: the kernels may use the sequence.
+static bool known_divisor_rounds_correctly(int side) {
+  static std::mutex mu;
+  static std::map<int, bool> checked;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = checked.find(side);
+  if (it != checked.end()) return it->second;
+  const float res = (float)(side - 1);
+  const volatile float c = 2.0f / res;
+  const float cc = c, r = 1.0f / cc;
+  bool ok = std::isfinite(r) && cc >= 0x1p-20f;
+  for (uint32_t m = 1u << 23; ok && m < (1u << 24); ++m) {
+    const float x = (float)m;
+    const float q = x * r;
+    const float q1 = std::fmaf(std::fmaf(-q, cc, x), r, q);
+    ok = q1 == x / cc;
+  }
+  checked[side] = ok;
+  return ok;
+}
+
 int pb_set_grid(pb_ctx* ctx, const float* sigma_t, int side) {
   if (!ctx || !sigma_t || side < 2 || side > 4096) { pb_set_error("pb_set_grid: bad argument (2 <= side <= 4096)"); return PB_ERR_ARG; }
   int rc = ensure_device(ctx);
   if (rc != PB_OK) return rc;
-  if (ctx->d_grid) { PB_HIP(hipFree(ctx->d_grid)); ctx->d_grid = nullptr; ctx->grid_side = 0; }
+  if (ctx->d_grid) { PB_HIP(hipFree(ctx->d_grid)); ctx->d_grid = nullptr; ctx->grid_side = 0; ctx->grid_fast_div = 0; }
   const size_t n = (size_t)side * side;
-  PB_HIP(hipMalloc(&ctx->d_grid, sizeof(float) * n));
-  PB_HIP(hipMemcpyAsync(ctx->d_grid, sigma_t, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+  // the field, then (16-byte aligned) the four values of every cell index: GridView::cells() in pb_grid.h
+  const size_t n_pad = (n + 3) & ~(size_t)3;
+  std::vector<float> host(n_pad + 4 * n, 0.0f);
+  std::memcpy(host.data(), sigma_t, sizeof(float) * n);
+  for (int row = 0; row < side; ++row)
+    for (int col = 0; col < side; ++col) {
+      const size_t i = (size_t)row * side + col;
+      float* c = host.data() + n_pad + 4 * i;
+      c[0] = sigma_t[i];
+      c[1] = (row + 1 < side) ? sigma_t[i + side] : sigma_t[i];
+      c[2] = (col + 1 < side) ? sigma_t[i + 1] : sigma_t[i];
+      c[3] = c[1];
+    }
+  PB_HIP(hipMalloc(&ctx->d_grid, sizeof(float) * host.size()));
+  PB_HIP(hipMemcpyAsync(ctx->d_grid, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, ctx->stream));
   PB_HIP(hipStreamSynchronize(ctx->stream));
   ctx->grid_side = side;
+  ctx->grid_fast_div = known_divisor_rounds_correctly(side) ? 1 : 0;
   return PB_OK;
 }
 

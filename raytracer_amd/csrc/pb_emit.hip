@@ -518,7 +518,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   ep.ctl = ctx->ctl; ep.seed = seed; ep.n_photons = n_photons;
   ep.cnt_const = cnt_const; ep.cnt_scatt = cnt_scatt; ep.off_const = off_const; ep.off_scatt = off_scatt;
   ep.dropped = totals + 3;
-  ep.grid.z = ctx->d_grid; ep.grid.side = ctx->grid_side;
+  ep.grid.z = ctx->d_grid; ep.grid.side = ctx->grid_side; ep.grid.fast_div = ctx->grid_fast_div;
   ep.sources = old_beams;
   const int blocks = (n_photons + EMIT_THREADS - 1) / EMIT_THREADS;
   if (n_photons > 0) {
@@ -570,7 +570,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   bp.beams = ctx->d_beams; bp.n_const = nc; bp.n_scatt = ns;
   bp.extinction_c = ctx->ctl.absorption_c + ctx->ctl.scattering_c;
   bp.heterogeneous = ctx->ctl.heterogeneous ? 1 : 0;
-  bp.grid.z = ctx->d_grid; bp.grid.side = ctx->grid_side;
+  bp.grid.z = ctx->d_grid; bp.grid.side = ctx->grid_side; bp.grid.fast_div = ctx->grid_fast_div;
   bp.seg_count = seg_count; bp.seg_offset = seg_offset;
   if (nb > 0) hipLaunchKernelGGL(bound_kernel<false>, dim3((nb + 255) / 256), dim3(256), 0, s, bp);
   PB_HIP(hipGetLastError());

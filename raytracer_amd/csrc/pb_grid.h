@@ -13,11 +13,16 @@
 struct GridView {
   const float* z;   // GRID.geometric_points[i].z, i = row * side + column
   int side;         // GRID.side_points
+  int fast_div;     // pb_set_grid found x / cell == fma(fma(-q, cell, x), r, q), q = x r, r = 1 / cell, for every x
+  // Behind the field, 16-byte aligned: per point (column, row) the four values sample() reads for a cell index
+  // inside the grid - {z[i], z[i + side] (z[i] in the last row), z[i + 1] (z[i] in the last column), the second
+  // again} - so that a sample costs one 16-byte load instead of four scattered ones.  pb_set_grid writes both.
+  PB_DI const float4* cells() const { return (const float4*)(z + (((size_t)side * side + 3) & ~(size_t)3)); }
 };
 
 struct DdaWalk {
   V3 o, dir, cell, delta, idx, prev;
-  float tx, ty, tz, t_max, res_x, res_y;
+  float tx, ty, tz, t_max, res_x, res_y, rcell;
   int state;        // 0: the sample at distance 0 is pending, 1: stepping, 2: finished
   int guard;
 
@@ -33,6 +38,7 @@ struct DdaWalk {
     dir = normalize3(d);
     res_x = (float)(g.side - 1); res_y = (float)(g.side - 1);
     cell = v3(2.0f / res_x, 2.0f / res_y, 2.0f / 2.0f);
+    rcell = 1.0f / cell.x;
     o = start - grid_min;
     t_max = length3(d);
     axis_setup(dir.x, o.x, cell.x, delta.x, tx);
@@ -49,16 +55,37 @@ struct DdaWalk {
     const V3 p = o + (dir * dist);
     const V3 mn = v3(cell.x * index.x, cell.y * index.y, cell.z * index.z);
     const V3 dl = p - mn;
-    const float prop_x = fabsf(dl.x) / cell.x, prop_y = fabsf(dl.y) / cell.y;
+    // x / cell by two fused multiply-adds where pb_set_grid has shown them to round like the division (cell.x
+    // and cell.y are the same number); an x below 2^-60 (other than zero), above 2^100 or not finite takes the division itself
+    const float ax = fabsf(dl.x), ay = fabsf(dl.y);
+    float prop_x, prop_y;
+    const uint32_t bx = __float_as_uint(ax), by = __float_as_uint(ay);      // zero (common at a crossing) or [2^-60, 2^100)
+    const bool in_range = (bx == 0u || bx - 0x21800000u < 0x50000000u) && (by == 0u || by - 0x21800000u < 0x50000000u);
+    if (g.fast_div && in_range) {
+      const float qx = ax * rcell, qy = ay * rcell;
+      prop_x = __builtin_fmaf(__builtin_fmaf(-qx, cell.x, ax), rcell, qx);
+      prop_y = __builtin_fmaf(__builtin_fmaf(-qy, cell.x, ay), rcell, qy);
+    } else {
+      asm volatile("");      // an empty statement the compiler may not run early: both divisions stay behind the branch
+      prop_x = ax / cell.x; prop_y = ay / cell.y;
+    }
     const int side = g.side, last = side * side - 1;
-    int t_l = (int)((index.y * side) + index.x);
-    int b_l = (int)(((index.y + 1) * side) + index.x);
-    if (index.y + 1 >= side) b_l = t_l;
-    int t_r = t_l + 1;
-    if (index.x + 1 >= side) t_r = t_l;
-    const int b_r = b_l;                       // Heterogeneous.h:158: the unbraced `b_r = b_l` always runs
-    t_l = min(max(t_l, 0), last); b_l = min(max(b_l, 0), last); t_r = min(max(t_r, 0), last);
-    const float tl = g.z[t_l], bl = g.z[b_l], tr = g.z[t_r], br = g.z[min(max(b_r, 0), last)];
+    const int ix = (int)index.x, iy = (int)index.y;
+    float tl, bl, tr, br;
+    if ((unsigned)ix < (unsigned)side && (unsigned)iy < (unsigned)side) {
+      // every index below stays inside the array, so the clamps are idle and the table holds the same four values
+      const float4 c = g.cells()[iy * side + ix];
+      tl = c.x; bl = c.y; tr = c.z; br = c.w;
+    } else {
+      int t_l = (int)((index.y * side) + index.x);
+      int b_l = (int)(((index.y + 1) * side) + index.x);
+      if (index.y + 1 >= side) b_l = t_l;
+      int t_r = t_l + 1;
+      if (index.x + 1 >= side) t_r = t_l;
+      const int b_r = b_l;                     // Heterogeneous.h:158: the unbraced `b_r = b_l` always runs
+      t_l = min(max(t_l, 0), last); b_l = min(max(b_l, 0), last); t_r = min(max(t_r, 0), last);
+      tl = g.z[t_l]; bl = g.z[b_l]; tr = g.z[t_r]; br = g.z[min(max(b_r, 0), last)];
+    }
     const float left = tl + ((bl - tl) * prop_y);
     const float right = tr + ((br - tr) * prop_y);
     float ext = left + ((right - left) * prop_x);

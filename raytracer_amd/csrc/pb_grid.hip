@@ -59,7 +59,7 @@ extern "C" int pb_extinction3d(pb_ctx* ctx, const float* start_xyz, const float*
   PB_HIP(hipMemcpyAsync(d_b, end_xyz, sizeof(float) * 3 * nn, hipMemcpyHostToDevice, s));
   if (n_samp) PB_HIP(hipMemsetAsync(d_samp, 0, sizeof(float) * n_samp, s));
   GridView g;
-  g.z = ctx->d_grid; g.side = ctx->grid_side;
+  g.z = ctx->d_grid; g.side = ctx->grid_side; g.fast_div = ctx->grid_fast_div;
   hipLaunchKernelGGL(extinction3d_kernel, dim3((n + 63) / 64), dim3(64), 0, s, g, d_a, d_b, n, d_mean, d_cnt, d_samp,
                      max_samples);
   PB_HIP(hipGetLastError());

@@ -109,6 +109,7 @@ struct RenderParams {
   uint32_t view_seed;      // Control seed: key of the camera rays' draws
   const float* grid_z;     // sigma_t field (side*side) or nullptr
   int grid_side;
+  int grid_fast_div;       // GridView::fast_div
   // geometry of this launch: tile (tx, k) covers pixels x = x0 + 8*tx + lx,
   // y = y0 + 8*k*strip_stride + ly; output row = 8*k + ly, row length out_w
   int x0, y0, out_w, out_h, strip_stride, tiles_x, tiles_y;
@@ -204,6 +205,7 @@ struct pb_ctx {
   // extinction field of the heterogeneous medium
   float* d_grid = nullptr;
   int grid_side = 0;
+  int grid_fast_div = 0;   // the cell size passed pb_set_grid's division check (GridView::fast_div)
   int n_seg = 0, cap_seg = 0, frame_mode = 0;
   bool bins_clean = false;   // every bin counter of the workspace is zero (left so by the last frame's finalize_kernel)
   bool have_segments = false;

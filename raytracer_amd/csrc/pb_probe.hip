@@ -191,7 +191,7 @@ extern "C" int pb_probe_pairs(pb_ctx* ctx, const pb_segment* segs, const float* 
   if (rc != PB_OK) return rc;
   GridView g;
   const bool generic_het = mode == PB_MODE_GENERIC && ctx->ctl.one_dimensional && ctx->ctl.heterogeneous && ctx->d_grid;
-  g.z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; g.side = ctx->grid_side;
+  g.z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; g.side = ctx->grid_side; g.fast_div = ctx->grid_fast_div;
   hipLaunchKernelGGL(probe_pair_kernel, dim3((n + 63) / 64), dim3(64), 0, s, d_frames, d_het, d_capA, d_capB, g, d_dir, n, mode,
                      ctx->ctl.one_dimensional, fast, ctx->ctl.absorption_c + ctx->ctl.scattering_c, ctx->ctl.scattering_c, d_cyl, d_int, d_status);
   PB_HIP(hipGetLastError());

@@ -380,7 +380,7 @@ PB_DI int eval_pair(const RenderParams& p, int sidx, const SegFrame& f, const Ra
     const PB_CONST_AS float* A = pb_uniform((const float*)p.capA) + 4 * (size_t)sidx;
     const PB_CONST_AS float* B = pb_uniform((const float*)p.capB) + 4 * (size_t)sidx;
     GridView grid;
-    grid.z = p.grid_z; grid.side = p.grid_side;
+    grid.z = p.grid_z; grid.side = p.grid_side; grid.fast_div = p.grid_fast_div;
     if (MODE == PB_MODE_GENERIC)
       return eval_pair_generic(f, hf, v3(A[0], A[1], A[2]), v3(B[0], B[1], B[2]), grid, p.one_dimensional != 0, r,
                                p.extinction_c, p.scattering_c, integral);
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const int nsub = p.ssaa * p.ssaa;
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
   GridView grid;
-  grid.z = p.grid_z; grid.side = p.grid_side;
+  grid.z = p.grid_z; grid.side = p.grid_side; grid.fast_div = p.grid_fast_div;
   for (uint32_t c = blockIdx.x; c < n_items; c += gridDim.x) {
     const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
     const int group = (int)it[0];
