@@ -47,13 +47,15 @@ int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
   if (ctx->d_capA) PB_HIP(hipFree(ctx->d_capA));
   if (ctx->d_capB) PB_HIP(hipFree(ctx->d_capB));
   if (ctx->d_het) PB_HIP(hipFree(ctx->d_het));
-  ctx->d_het = nullptr;
+  if (ctx->d_het_axis) PB_HIP(hipFree(ctx->d_het_axis));
+  ctx->d_het = nullptr; ctx->d_het_axis = nullptr;
   ctx->d_segs = nullptr; ctx->d_frames = nullptr; ctx->d_capA = nullptr; ctx->d_capB = nullptr; ctx->cap_seg = 0;
   PB_HIP(hipMalloc(&ctx->d_segs, sizeof(pb_segment) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_frames, sizeof(SegFrame) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_capA, sizeof(float4) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_capB, sizeof(float4) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_het, sizeof(HetFrame) * (size_t)cap));
+  PB_HIP(hipMalloc(&ctx->d_het_axis, sizeof(BeamAxis) * (size_t)cap));
   ctx->cap_seg = cap;
   return PB_OK;
 }
@@ -73,6 +75,10 @@ int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
   int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.one_dimensional, ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA,
                                       ctx->d_capB, ctx->d_het, s);
   if (rc != PB_OK) return rc;
+  if (mode != PB_MODE_721) {     // the estimators that go through Integral_73 / Integral_73Het
+    rc = pb_launch_beam_axis(ctx->d_capA, ctx->d_capB, ctx->d_het, ctx->n_seg, ctx->d_het_axis, s);
+    if (rc != PB_OK) return rc;
+  }
   PB_HIP(hipEventRecord(ctx->ev[3], s));
   ctx->ev_valid[1] = true;
   ctx->frame_mode = mode;
@@ -275,7 +281,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
   p.scattering_c = ctx->ctl.scattering_c;
   // Integral_73 reads the grid when HETEROGENEOUS is set (BeamRadiance.h:159-188)
   const bool generic_het = mode == PB_MODE_GENERIC && ctx->ctl.one_dimensional && ctx->ctl.heterogeneous;
-  p.het = ctx->d_het; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side; p.grid_fast_div = ctx->grid_fast_div;
+  p.het = ctx->d_het; p.het_axis = ctx->d_het_axis; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side; p.grid_fast_div = ctx->grid_fast_div;
   p.one_dimensional = ctx->ctl.one_dimensional;
   p.short_view = ctx->ctl.short_view; p.view_seed = ctx->ctl.seed;
   if (generic_het && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_GENERIC with one_dimensional and heterogeneous set needs pb_set_grid"); return PB_ERR_STATE; }
@@ -403,7 +409,7 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
-                  ctx->d_het, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
+                  ctx->d_het, ctx->d_het_axis, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
                   ctx->d_emit_tmp[1], ctx->d_rays, ctx->d_group_last,
                   ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->d_tile_u32, ctx->d_bin_list, ctx->d_bin_mask, ctx->d_items, ctx->d_accum,
                   ctx->d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,

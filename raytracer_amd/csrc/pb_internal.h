@@ -67,6 +67,15 @@ struct __attribute__((aligned(32))) HetFrame {
 };
 static_assert(sizeof(HetFrame) == 32, "HetFrame layout");
 
+// What Integral_73Het computes from the segment alone, in double: the unit axis, its dot product with itself, and
+// the distances of the two end points from orig_start.  Filled once per prepared segment set (beam_axis in
+// pb_pair.h) so that the per-hit code does not repeat three square roots and three divisions.
+struct BeamAxis {
+  double ab[3];
+  double u_dot_u, a_os, b_os;
+};
+static_assert(sizeof(BeamAxis) == 48, "BeamAxis layout");
+
 // A cone record's slot in the same array: cos^2 and sin^2 of HitCone's tan_theta (Intersections.h:184-200),
 // each the square, in double, of the float cosine / sine.
 struct __attribute__((aligned(32))) ConeFrame {
@@ -104,6 +113,7 @@ struct RenderParams {
   float extinction_c;      // Control.h:48
   float scattering_c;      // Control.h:47
   const HetFrame* het;     // per segment: Integral_73/73Het inputs, or a ConeFrame where qflags bit 5 is set
+  const BeamAxis* het_axis; // per segment: beam_axis() of its end points (unused values for a cone record)
   int one_dimensional;     // ONE_DIMENSIONAL, read by PB_MODE_GENERIC
   int short_view;          // SHORT_VIEW
   uint32_t view_seed;      // Control seed: key of the camera rays' draws
@@ -202,6 +212,7 @@ struct pb_ctx {
   float4* d_capA = nullptr;
   float4* d_capB = nullptr;
   HetFrame* d_het = nullptr;
+  BeamAxis* d_het_axis = nullptr;
   // extinction field of the heterogeneous medium
   float* d_grid = nullptr;
   int grid_side = 0;
@@ -274,6 +285,7 @@ int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matr
                             float4* d_screen_box, hipStream_t s);
 int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int one_dimensional, float scattering_c, SegFrame* d_frames,
                                float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s);
+int pb_launch_beam_axis(const float4* d_capA, const float4* d_capB, const HetFrame* d_het, int n, BeamAxis* d_out, hipStream_t s);
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);

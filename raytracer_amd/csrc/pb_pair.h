@@ -218,13 +218,25 @@ PB_DI double ddot(D3v a, D3v b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PB_DI double dlength(D3v a) { return __builtin_sqrt(ddot(a, a)); }
 PB_DI D3v dnormalize(D3v a) { return a * (1.0 / __builtin_sqrt(ddot(a, a))); }
 
-PB_DI double integral_73het(const GridView& grid, V3 seg_start, V3 seg_end, const HetFrame& hf, const CylHit& h,
+// The part of Integral_73Het that only the segment enters (BeamRadiance.h:218-219, :224, :252-254).
+PB_DI BeamAxis beam_axis(V3 seg_start, V3 seg_end, const HetFrame& hf) {
+  const D3v a = d3(seg_start), b = d3(seg_end);
+  const D3v ab = dnormalize(b - a);
+  const D3v os = d3(v3(hf.os[0], hf.os[1], hf.os[2]));
+  BeamAxis ax;
+  ax.ab[0] = ab.x; ax.ab[1] = ab.y; ax.ab[2] = ab.z;
+  ax.u_dot_u = ddot(ab, ab);
+  ax.a_os = dlength(a - os); ax.b_os = dlength(b - os);
+  return ax;
+}
+
+PB_DI double integral_73het(const GridView& grid, V3 seg_start, const HetFrame& hf, const BeamAxis& ax, const CylHit& h,
                             const Ray& r, float extinction_c, float scattering_c) {
   const D3v a = d3(seg_start), c = d3(h.exit);
-  const D3v b = d3(seg_end), d = d3(h.entry);
-  const D3v ab = dnormalize(b - a);
+  const D3v d = d3(h.entry);
+  D3v ab; ab.x = ax.ab[0]; ab.y = ax.ab[1]; ab.z = ax.ab[2];
   const D3v cd = dnormalize(d - c);
-  const double u_dot_u = ddot(ab, ab), u_dot_v = ddot(ab, cd), v_dot_v = ddot(cd, cd);
+  const double u_dot_u = ax.u_dot_u, u_dot_v = ddot(ab, cd), v_dot_v = ddot(cd, cd);
   const double u_dot_w = ddot(ab, a - c), v_dot_w = ddot(cd, a - c);
   const double denominator = u_dot_u * v_dot_v - u_dot_v * u_dot_v;
   if (!((denominator != 0) && (u_dot_u != 0) && (v_dot_v != 0))) return 0.0;
@@ -235,7 +247,7 @@ PB_DI double integral_73het(const GridView& grid, V3 seg_start, V3 seg_end, cons
   const D3v os = d3(v3(hf.os[0], hf.os[1], hf.os[2]));
   const double view_distance = dlength(point_view);
   const double beam_distance = dlength(point_beam - os);
-  const double a_os = dlength(a - os), b_os = dlength(b - os);
+  const double a_os = ax.a_os, b_os = ax.b_os;
   const bool bound1 = (view_distance >= dlength(d)) && (view_distance <= dlength(c));
   const bool bound2 = (beam_distance >= a_os) && (beam_distance <= b_os);
   if (!(bound1 && bound2)) return 0.0;
@@ -262,6 +274,11 @@ PB_DI double integral_73het(const GridView& grid, V3 seg_start, V3 seg_end, cons
   const double sin_theta = __builtin_sqrt(1 - cos_theta * cos_theta);
   const double rad = (double)(scattering / hf.radius);
   return transmitted * rad / sin_theta;
+}
+
+PB_DI double integral_73het(const GridView& grid, V3 seg_start, V3 seg_end, const HetFrame& hf, const CylHit& h,
+                            const Ray& r, float extinction_c, float scattering_c) {
+  return integral_73het(grid, seg_start, hf, beam_axis(seg_start, seg_end, hf), h, r, extinction_c, scattering_c);
 }
 
 // One (ray, segment) pair of BVHBeamRadianceHet (BeamRadiance.h:378-398).

@@ -1124,8 +1124,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         if (long_form) {
           const HetFrame hf = p.het[sidx];
-          const float4 A = p.capA[sidx], B = p.capB[sidx];
-          integral = integral_73het(grid, v3(A.x, A.y, A.z), v3(B.x, B.y, B.z), hf, h, rq, p.extinction_c, p.scattering_c);
+          const float4 A = p.capA[sidx];
+          integral = integral_73het(grid, v3(A.x, A.y, A.z), hf, p.het_axis[sidx], h, rq, p.extinction_c, p.scattering_c);
         }
       }
       if (mine) {
@@ -1178,6 +1178,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     __syncthreads();   // surv, the queue and the sums are rewritten by the next item
   }
+}
+
+__global__ __launch_bounds__(256) void beam_axis_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
+                                                       const HetFrame* __restrict__ het, int n, BeamAxis* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 A = capA[i], B = capB[i];
+  out[i] = beam_axis(v3(A.x, A.y, A.z), v3(B.x, B.y, B.z), het[i]);
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
@@ -1320,6 +1328,13 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   else hipLaunchKernelGGL(eval_bins_fast_kernel, dim3(waves), dim3(64), 0, s, p);
   const size_t px = (size_t)p.out_w * p.out_h;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, p);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}
+
+int pb_launch_beam_axis(const float4* d_capA, const float4* d_capB, const HetFrame* d_het, int n, BeamAxis* d_out, hipStream_t s) {
+  if (n <= 0) return PB_OK;
+  hipLaunchKernelGGL(beam_axis_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_capA, d_capB, d_het, n, d_out);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }
