@@ -61,11 +61,10 @@ struct DdaWalk {
     float prop_x, prop_y;
     const uint32_t bx = __float_as_uint(ax), by = __float_as_uint(ay);      // zero (common at a crossing) or [2^-60, 2^100)
     const bool in_range = (bx == 0u || bx - 0x21800000u < 0x50000000u) && (by == 0u || by - 0x21800000u < 0x50000000u);
-    if (g.fast_div && in_range) {
-      const float qx = ax * rcell, qy = ay * rcell;
-      prop_x = __builtin_fmaf(__builtin_fmaf(-qx, cell.x, ax), rcell, qx);
-      prop_y = __builtin_fmaf(__builtin_fmaf(-qy, cell.x, ay), rcell, qy);
-    } else {
+    const float qx = ax * rcell, qy = ay * rcell;
+    prop_x = __builtin_fmaf(__builtin_fmaf(-qx, cell.x, ax), rcell, qx);
+    prop_y = __builtin_fmaf(__builtin_fmaf(-qy, cell.x, ay), rcell, qy);
+    if (__builtin_expect(!(g.fast_div && in_range), 0)) {
       asm volatile("");      // an empty statement the compiler may not run early: both divisions stay behind the branch
       prop_x = ax / cell.x; prop_y = ay / cell.y;
     }
