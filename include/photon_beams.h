@@ -166,7 +166,10 @@ int pb_create_surface(int triangle_number, float height, double time, float* poi
 void pb_transform_points(const float matrix[16], float* points_xyzw, int n);
 
 /* The extinction field that Extinction3D reads (Heterogeneous.h:152-163): GRID.geometric_points[i].z
- * after HeterogeneousRun's transform, side*side values, i = row * side + column, side = GRID.side_points. */
+ * after HeterogeneousRun's transform, side*side values, i = row * side + column, side = GRID.side_points.
+ * 2 <= side <= 4096.  The first call with a given side in a process also checks on the host (about 50 ms)
+ * that the kernels' two-multiply-add form of x / (2 / (side - 1)) rounds like the division for every x;
+ * where it does not, they divide.  Results do not depend on the outcome. */
 int pb_set_grid(pb_ctx* ctx, const float* sigma_t, int side);
 
 /* Extinction3D (Heterogeneous.h:29-135) for n rays at once: start/end are xyz triples in camera space.
