@@ -266,9 +266,28 @@ __global__ __launch_bounds__(256) void node_box_kernel(const RefitLevels lv, int
     int level = 0;
     long long size = 1;
     while (level + 1 < lv.n_levels && (i % (size * 64) == 0) && (i + size * 64 - 1 <= last)) { size *= 64; level++; }
-    const float* b = lv.box[level] + (size_t)(i / size) * 6;
-    for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], b[k]); hi[k] = fmaxf(hi[k], b[3 + k]); }
-    i += size;
+    // Entries of this level from i on: up to the last one that lies inside the range, but not past the next
+    // multiple of 64 entries, where the level is chosen anew.  Four entries are requested before the first is
+    // used (an index past the run repeats its last entry, which changes no union): the loop waits for memory
+    // once per four entries, and that wait is what the kernel's time consists of.
+    const long long k0 = i / size;
+    const long long k_fit = (last + 1) / size - 1;
+    const long long k_end = (k0 | 63) < k_fit ? (k0 | 63) : k_fit;
+    const float* base = lv.box[level];
+    for (long long k = k0; k <= k_end; k += 4) {
+      float v[4][6];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long e = (k + u < k_end) ? k + u : k_end;
+        const float* b = base + (size_t)e * 6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[u][c] = b[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[u][c]); hi[c] = fmaxf(hi[c], v[u][3 + c]); }
+    }
+    i = (k_end + 1) * size;
   }
   for (int k = 0; k < 3; ++k) { node_box[(size_t)node * 6 + k] = lo[k]; node_box[(size_t)node * 6 + 3 + k] = hi[k]; }
 }
