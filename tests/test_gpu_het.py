@@ -50,6 +50,37 @@ def test_extinction3d_samples_are_bit_exact(pb):
     assert cnt[:100].mean() > 10     # the camera rays do cross many cells
 
 
+@pytest.mark.parametrize("side", [2, 10, 33, 64])
+def test_extinction3d_other_grid_sides_and_odd_rays(pb, side):
+    """Fields of other sizes (the per-cell table behind the field and the cell-size division are built per side),
+    with negative values (clamped to 0 by the sample), rays that start outside the grid in x / y (cell indices
+    outside the table), on cell corners and on the grid's edge (zero offsets within the cell).  (A ray of zero length
+    has a NaN direction and never ends in the reference; only the iteration caps end it here, so it is left out.)"""
+    rng = np.random.default_rng(100 + side)
+    sigma = rng.uniform(-0.02, 0.08, side * side).astype(np.float32)
+    n = 240
+    starts = np.column_stack([rng.uniform(-0.95, 0.95, n), rng.uniform(-0.95, 0.95, n), rng.uniform(2.05, 3.95, n)])
+    ends = np.column_stack([rng.uniform(-0.99, 0.99, n), rng.uniform(-0.99, 0.99, n), rng.uniform(2.01, 3.99, n)])
+    starts[:40, 0] = rng.uniform(-1.6, -1.05, 40)                 # left of the grid
+    starts[40:80, 1] = rng.uniform(1.05, 1.6, 40)                 # above it
+    cell = np.float32(2.0) / np.float32(side - 1)
+    corner = rng.integers(0, side - 1, (40, 2))
+    starts[80:120, 0] = (cell * corner[:, 0].astype(np.float32)).astype(np.float64) - 1.0   # on cell corners
+    starts[80:120, 1] = (cell * corner[:, 1].astype(np.float32)).astype(np.float64) - 1.0
+    starts[120:140, 0] = -1.0; starts[140:160, 1] = 1.0           # on the grid's edge
+    starts = starts.astype(np.float32); ends = ends.astype(np.float32)
+    with pb.Context(het_control(pb)) as ctx:
+        ctx.set_scene()
+        ctx.set_grid(sigma, side)
+        mean, cnt, samp = ctx.extinction3d(starts, ends, max_samples=400)
+    for i in range(n):
+        om, ode = orc.extinction3d(sigma, side, list(starts[i]) + [1.0], list(ends[i]) + [1.0])
+        assert len(ode) == cnt[i], i
+        k = min(cnt[i], 400)
+        assert np.array_equal(samp[i, :k], ode[:k], equal_nan=True), i
+        assert mean[i] == om or (np.isnan(mean[i]) and np.isnan(om)), i
+
+
 def test_het_photon_pass_matches_oracle(pb):
     n_photons, bounces = 1500, 2
     octl = het_control(orc, photon_number=n_photons, bounces=bounces)
