@@ -38,17 +38,17 @@ def _worker(rank, world, port, height, width, out_dir):
         frame = torch.zeros((height, width, 3), dtype=torch.float32)
         tiles.gather_frame(mine, gathered, frame, world)
         assert np.array_equal(frame.numpy(), full), "reassembled frame differs"
-        # pipelined gather: five "frames" (frame k = full + k), two in flight
+        # pipelined gather: forty "frames" (frame k = full + k), two in flight
         pipe = tiles.StripPipeline(world, n * 8, width, torch.device("cpu"))
         seen = []
-        for k in range(5):
+        for k in range(40):
             slot = pipe.begin(frame)
             if k >= 2:
                 seen.append(frame.numpy().copy())        # frame k - 2 has just been completed
             pipe.mine[slot].copy_(torch.from_numpy(full[rows] + np.float32(k)))
             pipe.submit(slot)
         pipe.drain(frame)
-        assert np.array_equal(frame.numpy(), full + np.float32(4)), "last pipelined frame differs"
+        assert np.array_equal(frame.numpy(), full + np.float32(39)), "last pipelined frame differs"
         for k, got in enumerate(seen):
             assert np.array_equal(got, full + np.float32(k)), f"pipelined frame {k} differs"
         # segment broadcast
