@@ -146,6 +146,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # a rank stuck in a collective would hold the whole job: say where it stands and end instead
+        import faulthandler
+        faulthandler.dump_traceback_later(600, exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -281,6 +284,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
     ctx.close()
 
 
