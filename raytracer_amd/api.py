@@ -66,6 +66,20 @@ def library_path():
     return _LIB_PATH
 
 
+def source_stamp():
+    """sha256 (first 16 hex digits) over the kernel sources in raytracer_amd/csrc, in name order: names the
+    build that a committed profile was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _preload_hip_runtime():
     """libphoton_beams.so carries no HIP runtime of its own: make the process's one visible first.
     In a process that can import torch that is the runtime bundled with torch (so that torch tensors,

@@ -6,6 +6,8 @@ rank s % world: interleaved, because the lit cone is centred and rows differ in 
 Two exchange steps exist: the segment set is broadcast once from the rank that emitted it, and the
 rendered strips are all-gathered per frame.  Nothing here touches the GPU path itself, so the same code
 runs over RCCL ("nccl" backend, device tensors) and over gloo (CPU tensors, used by the tests)."""
+import datetime
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -47,30 +49,48 @@ def gather_frame(mine, gathered, frame, world):
     return assemble(gathered, frame)
 
 
+class StripStall(RuntimeError):
+    """A strip gather did not finish within the pipeline's time limit."""
+
+
 class StripPipeline:
-    """Double-buffered all-gather of the ranks' strips: the gather of frame k runs on the collective's
-    own stream while frame k + 1 is rendered, so the exchange is hidden behind compute.  Every frame is still
-    rendered, gathered and put in image order; only the order of the waits changes.
+    """All-gather of the ranks' strips, pipelined where the backend allows it.
+
+    Over RCCL ("nccl" backend, device tensors) the gather of frame k runs on the collective's own stream
+    while frame k + 1 is rendered (two slots), so the exchange is hidden behind compute; a gather that
+    never finishes is ended by the process group's own time limit (init_process_group(timeout=...)).
+    Over any other backend (gloo: host tensors, and device tensors only through staging copies that
+    have been seen to stall with more than one gather outstanding) every gather goes through host
+    buffers, one at a time, and waits at most `timeout_s` before raising StripStall with rank, slot and
+    frame.  Every frame is rendered, gathered and put in image order either way; only the order of
+    the waits differs.
 
         pipe = StripPipeline(world, rows_per_rank, width, device)
         for k in range(frames):
-            slot = pipe.begin(frame)          # finishes the frame that used this slot two steps ago
+            slot = pipe.begin(frame)          # finishes the frame that used this slot `depth` steps ago
             render into pipe.mine[slot]
             pipe.submit(slot)
         pipe.drain(frame)
     """
 
-    def __init__(self, world, rows, width, device, channels=3, depth=2, frame=None):
+    def __init__(self, world, rows, width, device, channels=3, depth=2, frame=None, timeout_s=120.0):
         self.world = world
-        self.depth = depth
+        self.timeout_s = timeout_s
+        backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else None
+        self.overlapped = backend == "nccl"
+        self.depth = depth if (world == 1 or self.overlapped) else 1
         # one rank owns every strip: it renders straight into the frame, nothing to exchange or copy
         self.direct = world == 1 and frame is not None and tuple(frame.shape) == (rows, width, channels)
         self.mine = [frame if self.direct else torch.zeros((rows, width, channels), dtype=torch.float32, device=device)
-                     for _ in range(depth)]
+                     for _ in range(self.depth)]
         self.gathered = [torch.zeros((world, rows, width, channels), dtype=torch.float32, device=device)
-                         if world > 1 else None for _ in range(depth)]
-        self.work = [None] * depth
-        self.filled = [False] * depth
+                         if world > 1 else None for _ in range(self.depth)]
+        self.staged = world > 1 and not self.overlapped
+        if self.staged:
+            self.h_mine = torch.zeros((rows, width, channels), dtype=torch.float32)
+            self.h_gathered = torch.zeros((world * rows, width, channels), dtype=torch.float32)
+        self.work = [None] * self.depth
+        self.filled = [False] * self.depth
         self.k = 0
 
     def _finish(self, slot, frame):
@@ -80,7 +100,9 @@ class StripPipeline:
             if not self.direct:
                 frame.copy_(self.mine[slot])
         else:
-            self.work[slot].wait()            # the current stream waits for that gather; the host does not
+            if self.work[slot] is not None:
+                self.work[slot].wait()        # RCCL: the current stream waits for that gather; the host does not
+                self.work[slot] = None
             assemble(self.gathered[slot], frame)
         self.filled[slot] = False
 
@@ -92,13 +114,40 @@ class StripPipeline:
     def submit(self, slot):
         if self.world > 1:
             g = self.gathered[slot]
-            self.work[slot] = dist.all_gather_into_tensor(g.view(-1, *g.shape[2:]), self.mine[slot], async_op=True)
+            if self.overlapped:
+                self.work[slot] = dist.all_gather_into_tensor(g.view(-1, *g.shape[2:]), self.mine[slot], async_op=True)
+            else:
+                # host-staged and complete before submit returns: never more than one gather outstanding
+                self.h_mine.copy_(self.mine[slot])
+                work = dist.all_gather_into_tensor(self.h_gathered, self.h_mine, async_op=True)
+                try:
+                    done = work.wait(timeout=datetime.timedelta(seconds=self.timeout_s))
+                except RuntimeError as e:
+                    raise StripStall(f"rank {dist.get_rank()}: strip gather of frame {self.k} (slot {slot}) failed or "
+                                     f"timed out after {self.timeout_s:.0f} s: {e}") from e
+                if done is False:
+                    raise StripStall(f"rank {dist.get_rank()}: strip gather of frame {self.k} (slot {slot}) did not "
+                                     f"finish within {self.timeout_s:.0f} s")
+                g.view(-1, *g.shape[2:]).copy_(self.h_gathered)
         self.filled[slot] = True
         self.k += 1
 
     def drain(self, frame):
         for d in range(self.depth):
             self._finish((self.k + d) % self.depth, frame)
+
+
+def run_steps(pipe, frame, render, steps, first=0, on_step=None):
+    """The frame loop of bench.py: `steps` frames through `pipe`, frame i rendered by render(mine, i) into this
+    rank's packed strips, then every frame still in flight completed.  on_step(i) runs after frame i has been
+    submitted (bench.py re-arms its standstill watchdog there)."""
+    for i in range(first, first + steps):
+        slot = pipe.begin(frame)
+        render(pipe.mine[slot], i)
+        pipe.submit(slot)
+        if on_step is not None:
+            on_step(i)
+    pipe.drain(frame)
 
 
 def broadcast_segments(segs, root_box, device, src=0, itemsize=112):

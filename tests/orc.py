@@ -117,8 +117,13 @@ def lib():
 _ref = None
 
 
+def ref_available():
+    """Whether oracle/_ref is built (nothing is loaded by asking)."""
+    return os.path.exists(REF_SO)
+
+
 def ref():
-    """The reference's own functions, or None where oracle/_ref is not built."""
+    """The reference's own functions, or None where oracle/_ref is not built.  Loaded on first use only."""
     global _ref
     if _ref is None and os.path.exists(REF_SO):
         _ref = C.CDLL(REF_SO)

@@ -114,7 +114,7 @@ def test_find_rotation_matrix_bit_exact(gold):
     assert_bit_equal(m, gold["rot_m"], "findRotationMatrix")
 
 
-@pytest.mark.skipif(orc.ref() is None, reason="oracle/_ref (the reference's own functions) is not built here")
+@pytest.mark.skipif(not orc.ref_available(), reason="oracle/_ref (the reference's own functions) is not built here")
 def test_primitives_live_against_reference():
     """Fresh seeds against the reference's functions themselves (only where /root/reference exists)."""
     rng = np.random.default_rng(7)

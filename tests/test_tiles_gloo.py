@@ -38,19 +38,28 @@ def _worker(rank, world, port, height, width, out_dir):
         frame = torch.zeros((height, width, 3), dtype=torch.float32)
         tiles.gather_frame(mine, gathered, frame, world)
         assert np.array_equal(frame.numpy(), full), "reassembled frame differs"
-        # pipelined gather: forty "frames" (frame k = full + k), two in flight
-        pipe = tiles.StripPipeline(world, n * 8, width, torch.device("cpu"))
+        # pipelined gather: forty "frames" (frame k = full + k); over gloo the pipeline keeps one gather in
+        # flight and stages it through host buffers, over RCCL two
+        pipe = tiles.StripPipeline(world, n * 8, width, torch.device("cpu"), timeout_s=60)
+        assert pipe.depth == 1 and pipe.staged
         seen = []
         for k in range(40):
             slot = pipe.begin(frame)
-            if k >= 2:
-                seen.append(frame.numpy().copy())        # frame k - 2 has just been completed
+            if k >= pipe.depth:
+                seen.append(frame.numpy().copy())        # frame k - depth has just been completed
             pipe.mine[slot].copy_(torch.from_numpy(full[rows] + np.float32(k)))
             pipe.submit(slot)
         pipe.drain(frame)
         assert np.array_equal(frame.numpy(), full + np.float32(39)), "last pipelined frame differs"
         for k, got in enumerate(seen):
             assert np.array_equal(got, full + np.float32(k)), f"pipelined frame {k} differs"
+        # the frame loop bench.py itself runs (tiles.run_steps), 40 frames, with its per-step hook
+        pipe = tiles.StripPipeline(world, n * 8, width, torch.device("cpu"), timeout_s=60)
+        steps_seen = []
+        tiles.run_steps(pipe, frame, lambda mine, i: mine.copy_(torch.from_numpy(full[rows] * np.float32(2) + np.float32(i))),
+                        40, on_step=steps_seen.append)
+        assert steps_seen == list(range(40))
+        assert np.array_equal(frame.numpy(), full * np.float32(2) + np.float32(39)), "run_steps: last frame differs"
         # segment broadcast
         segs = None
         root = None
@@ -73,6 +82,31 @@ def test_strips_gather_and_broadcast_over_gloo(world, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, 64, 40, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), f"ok{r}")) for r in range(world))
+
+
+def _stall_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pipe = tiles.StripPipeline(world, 8, 16, torch.device("cpu"), timeout_s=3)
+    frame = torch.zeros((16, 16, 3), dtype=torch.float32)
+    if rank == 0:
+        try:
+            tiles.run_steps(pipe, frame, lambda mine, i: mine.fill_(1.0), 1)
+            open(os.path.join(out_dir, "no_error"), "w").write("x")
+        except tiles.StripStall as e:
+            open(os.path.join(out_dir, "stalled"), "w").write(str(e))
+    else:
+        import time
+        time.sleep(8)            # never joins the gather
+    os._exit(0)                  # the group holds a gather that cannot complete: leave without tearing it down
+
+
+def test_a_gather_that_stalls_raises_instead_of_blocking(tmp_path):
+    port = _free_port()
+    mp.spawn(_stall_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    msg = open(os.path.join(str(tmp_path), "stalled")).read()
+    assert "rank 0" in msg and "frame 0" in msg and "slot 0" in msg
 
 
 def test_strip_bookkeeping():
