@@ -398,6 +398,11 @@ class Context:
                                   C.c_int(self._cull(use_lbvh, cull)), C.c_void_p(d_out_ptr), C.c_void_p(stream)),
                "pb_render_d")
 
+    def draw_noalloc_device(self, d_out_ptr, x0, y0, w, h, mode=MODE_721, stream=0):
+        """pb_render_noalloc_d: draw_device(cull="bins") without any allocation (fixed static workspace)."""
+        _check(self.L.pb_render_noalloc_d(self.h, C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h), C.c_int(mode),
+                                          C.c_void_p(d_out_ptr), C.c_void_p(stream)), "pb_render_noalloc_d")
+
     def draw_strips_device(self, d_out_ptr, first_strip, strip_stride, n_strips, mode=MODE_721, use_lbvh=False,
                            stream=0, cull=None):
         _check(self.L.pb_render_strips_d(self.h, C.c_int(first_strip), C.c_int(strip_stride), C.c_int(n_strips),

@@ -37,6 +37,65 @@ void host_gate_setup(const float lo[3], const float hi[3], GateBox& g) {
   g.qflags = q;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The workspace of pb_render_noalloc_d: one file-scope device array per GPU (every GPU the library runs on holds
+// its own copy at its own address until the process ends), laid out once per device by static_workspace_init.
+// In host code `scratch` is only a handle for hipGetSymbolAddress; kernels and memsets get the address it returns.
+// ---------------------------------------------------------------------------------------------------------
+constexpr size_t NOALLOC_SLOTS = 2 * (size_t)PB_NOALLOC_MAX_GROUPS;     // queue slots (macro tiles are padded to 64 tiles)
+constexpr size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+constexpr size_t SCRATCH_CTRL = 0;
+constexpr size_t SCRATCH_RAYS = SCRATCH_CTRL + 256;
+constexpr size_t SCRATCH_GROUP_LAST = SCRATCH_RAYS + align256(sizeof(float) * PB_RAY_WORDS * 64 * (size_t)PB_NOALLOC_MAX_GROUPS);
+constexpr size_t SCRATCH_TILE_U32 = SCRATCH_GROUP_LAST + align256(sizeof(int) * (size_t)PB_NOALLOC_MAX_GROUPS);
+constexpr size_t SCRATCH_SCAN_TMP = SCRATCH_TILE_U32 + align256(sizeof(uint32_t) * (4 + 3 * (size_t)PB_BIN_SUBS) * NOALLOC_SLOTS);
+constexpr size_t SCRATCH_BIN_LIST = SCRATCH_SCAN_TMP + align256(sizeof(uint32_t) * (NOALLOC_SLOTS * PB_BIN_SUBS / 256 + 64));
+constexpr size_t SCRATCH_BIN_MASK = SCRATCH_BIN_LIST + align256(sizeof(uint32_t) * (size_t)PB_NOALLOC_MAX_LIST_ENTRIES);
+constexpr size_t SCRATCH_ITEMS = SCRATCH_BIN_MASK + align256(sizeof(unsigned long long) * PB_BIN_FAN * (size_t)PB_NOALLOC_MAX_SEGMENTS);
+constexpr size_t SCRATCH_ACCUM = SCRATCH_ITEMS + align256(sizeof(uint32_t) * 4 * (size_t)PB_NOALLOC_MAX_ITEMS);
+constexpr size_t SCRATCH_BYTES = SCRATCH_ACCUM + align256(sizeof(unsigned long long) * 3 * 64 * (size_t)PB_NOALLOC_MAX_GROUPS);
+static_assert(SCRATCH_BYTES <= (size_t)PB_NOALLOC_SCRATCH_BYTES, "the layout must fit the stated size of the static workspace");
+
+static __device__ __align__(256) unsigned char scratch[PB_NOALLOC_SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+struct StaticWorkspace { unsigned char* base = nullptr; FrameWorkspace ws; };
+StaticWorkspace g_static[MAX_DEVICES];
+std::mutex g_static_mu;
+
+// With `device` current: the address of this GPU's copy of `scratch`, and the fixed workspace laid out in it.
+int static_workspace_init(int device) {
+  if (device < 0 || device >= MAX_DEVICES) { pb_set_error("pb_create: device index beyond the static workspace table"); return PB_ERR_ARG; }
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  StaticWorkspace& sw = g_static[device];
+  if (sw.base) return PB_OK;
+  void* ptr = nullptr;
+  PB_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) { pb_set_error("pb_create: hipGetSymbolAddress returned no address for the static workspace"); return PB_ERR_DEVICE; }
+  unsigned char* b = (unsigned char*)ptr;
+  FrameWorkspace& ws = sw.ws;
+  ws.fixed = true;
+  ws.d_ctrl = (uint32_t*)(b + SCRATCH_CTRL);
+  ws.d_rays = (float*)(b + SCRATCH_RAYS);
+  ws.d_group_last = (int*)(b + SCRATCH_GROUP_LAST);
+  ws.ws_groups = PB_NOALLOC_MAX_GROUPS;
+  ws.ws_chunks = 0;                       // the ordered cull modes are not served from the static workspace
+  ws.d_tile_u32 = (uint32_t*)(b + SCRATCH_TILE_U32);
+  ws.d_scan_tmp = (uint32_t*)(b + SCRATCH_SCAN_TMP);
+  ws.ws_tiles = (int)NOALLOC_SLOTS;
+  ws.d_bin_list = (uint32_t*)(b + SCRATCH_BIN_LIST);
+  ws.ws_bin_cap = PB_NOALLOC_MAX_LIST_ENTRIES;
+  ws.d_bin_mask = (unsigned long long*)(b + SCRATCH_BIN_MASK);
+  ws.ws_mask_cap = (size_t)PB_BIN_FAN * PB_NOALLOC_MAX_SEGMENTS;
+  ws.d_items = (uint32_t*)(b + SCRATCH_ITEMS);
+  ws.ws_item_cap = PB_NOALLOC_MAX_ITEMS;
+  ws.d_accum = (unsigned long long*)(b + SCRATCH_ACCUM);
+  ws.ws_accum_px = (size_t)64 * PB_NOALLOC_MAX_GROUPS;
+  sw.base = b;
+  return PB_OK;
+}
+
 }  // namespace
 
 int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
@@ -89,73 +148,102 @@ int pb_default_mode(const pb_ctx* ctx) { return default_mode(ctx); }
 
 namespace {
 
-int ensure_workspace(pb_ctx* ctx, int groups, int chunks) {
-  if (groups > ctx->ws_groups) {
-    if (ctx->d_rays) PB_HIP(hipFree(ctx->d_rays));
-    if (ctx->d_group_last) PB_HIP(hipFree(ctx->d_group_last));
-    ctx->d_rays = nullptr; ctx->d_group_last = nullptr; ctx->ws_groups = 0;
-    PB_HIP(hipMalloc(&ctx->d_rays, sizeof(float) * PB_RAY_WORDS * 64 * (size_t)groups));
-    PB_HIP(hipMalloc(&ctx->d_group_last, sizeof(int) * (size_t)groups));
-    ctx->ws_groups = groups;
+// A need beyond a fixed workspace is an error of the caller's frame, named so that it can be told what to shrink.
+int beyond_fixed(const char* what, size_t need, size_t cap) {
+  pb_set_error(std::string("pb_render_noalloc_d: the frame needs ") + std::to_string(need) + " " + what +
+               ", the static workspace holds " + std::to_string(cap) + " (see PB_NOALLOC_* in photon_beams.h)");
+  return PB_ERR_CAPACITY;
+}
+
+int ensure_workspace(FrameWorkspace& ws, int groups, int chunks) {
+  if (ws.fixed) {
+    if (groups > ws.ws_groups) return beyond_fixed("ray groups (8x8-pixel tiles x sub-samples)", (size_t)groups, (size_t)ws.ws_groups);
+    if (chunks > ws.ws_chunks) return beyond_fixed("candidate chunks", (size_t)chunks, (size_t)ws.ws_chunks);
+    return PB_OK;
   }
-  if (chunks > ctx->ws_chunks) {
-    if (ctx->d_chunks) PB_HIP(hipFree(ctx->d_chunks));
-    if (ctx->d_partials) PB_HIP(hipFree(ctx->d_partials));
-    ctx->d_chunks = nullptr; ctx->d_partials = nullptr; ctx->ws_chunks = 0;
-    PB_HIP(hipMalloc(&ctx->d_chunks, sizeof(uint32_t) * PB_CHUNK_WORDS * (size_t)chunks));
-    PB_HIP(hipMalloc(&ctx->d_partials, sizeof(double) * 3 * 64 * (size_t)chunks));
-    ctx->ws_chunks = chunks;
+  if (groups > ws.ws_groups) {
+    if (ws.d_rays) PB_HIP(hipFree(ws.d_rays));
+    if (ws.d_group_last) PB_HIP(hipFree(ws.d_group_last));
+    ws.d_rays = nullptr; ws.d_group_last = nullptr; ws.ws_groups = 0;
+    PB_HIP(hipMalloc(&ws.d_rays, sizeof(float) * PB_RAY_WORDS * 64 * (size_t)groups));
+    PB_HIP(hipMalloc(&ws.d_group_last, sizeof(int) * (size_t)groups));
+    ws.ws_groups = groups;
+  }
+  if (chunks > ws.ws_chunks) {
+    if (ws.d_chunks) PB_HIP(hipFree(ws.d_chunks));
+    if (ws.d_partials) PB_HIP(hipFree(ws.d_partials));
+    ws.d_chunks = nullptr; ws.d_partials = nullptr; ws.ws_chunks = 0;
+    PB_HIP(hipMalloc(&ws.d_chunks, sizeof(uint32_t) * PB_CHUNK_WORDS * (size_t)chunks));
+    PB_HIP(hipMalloc(&ws.d_partials, sizeof(double) * 3 * 64 * (size_t)chunks));
+    ws.ws_chunks = chunks;
   }
   return PB_OK;
 }
 
-int ensure_bin_workspace(pb_ctx* ctx, int tiles, int bin_cap, int item_cap, size_t accum_px) {
-  if (tiles > ctx->ws_tiles) {
-    if (ctx->d_tile_u32) PB_HIP(hipFree(ctx->d_tile_u32));
-    if (ctx->d_scan_tmp) PB_HIP(hipFree(ctx->d_scan_tmp));
-    ctx->d_tile_u32 = nullptr; ctx->d_scan_tmp = nullptr; ctx->ws_tiles = 0; ctx->bins_clean = false;
-    PB_HIP(hipMalloc(&ctx->d_tile_u32, sizeof(uint32_t) * (4 + 3 * (size_t)PB_BIN_SUBS) * (size_t)tiles));   // macro tiles <= tiles
-    PB_HIP(hipMalloc(&ctx->d_scan_tmp, sizeof(uint32_t) * pb_scan_tmp_words(tiles * PB_BIN_SUBS)));
-    ctx->ws_tiles = tiles;
+int ensure_bin_workspace(FrameWorkspace& ws, int tiles, int bin_cap, int item_cap, size_t accum_px) {
+  if (ws.fixed) {
+    if (tiles > ws.ws_tiles) return beyond_fixed("queue slots (64 per 64x64-pixel macro tile)", (size_t)tiles, (size_t)ws.ws_tiles);
+    if (bin_cap > ws.ws_bin_cap) return beyond_fixed("macro-tile list entries", (size_t)bin_cap, (size_t)ws.ws_bin_cap);
+    if (item_cap > ws.ws_item_cap) return beyond_fixed("evaluation items", (size_t)item_cap, (size_t)ws.ws_item_cap);
+    if (accum_px > ws.ws_accum_px) return beyond_fixed("pixel sums", accum_px, ws.ws_accum_px);
+    return PB_OK;
   }
-  if (bin_cap > ctx->ws_bin_cap) {
-    if (ctx->d_bin_list) PB_HIP(hipFree(ctx->d_bin_list));
-    ctx->d_bin_list = nullptr; ctx->ws_bin_cap = 0;
-    PB_HIP(hipMalloc(&ctx->d_bin_list, sizeof(uint32_t) * (size_t)bin_cap));
-    ctx->ws_bin_cap = bin_cap;
+  if (tiles > ws.ws_tiles) {
+    if (ws.d_tile_u32) PB_HIP(hipFree(ws.d_tile_u32));
+    if (ws.d_scan_tmp) PB_HIP(hipFree(ws.d_scan_tmp));
+    ws.d_tile_u32 = nullptr; ws.d_scan_tmp = nullptr; ws.ws_tiles = 0; ws.bins_clean = false;
+    PB_HIP(hipMalloc(&ws.d_tile_u32, sizeof(uint32_t) * (4 + 3 * (size_t)PB_BIN_SUBS) * (size_t)tiles));   // macro tiles <= tiles
+    PB_HIP(hipMalloc(&ws.d_scan_tmp, sizeof(uint32_t) * pb_scan_tmp_words(tiles * PB_BIN_SUBS)));
+    ws.ws_tiles = tiles;
   }
-  if (item_cap > ctx->ws_item_cap) {
-    if (ctx->d_items) PB_HIP(hipFree(ctx->d_items));
-    ctx->d_items = nullptr; ctx->ws_item_cap = 0;
-    PB_HIP(hipMalloc(&ctx->d_items, sizeof(uint32_t) * 4 * (size_t)item_cap));
-    ctx->ws_item_cap = item_cap;
+  if (bin_cap > ws.ws_bin_cap) {
+    if (ws.d_bin_list) PB_HIP(hipFree(ws.d_bin_list));
+    ws.d_bin_list = nullptr; ws.ws_bin_cap = 0;
+    PB_HIP(hipMalloc(&ws.d_bin_list, sizeof(uint32_t) * (size_t)bin_cap));
+    ws.ws_bin_cap = bin_cap;
   }
-  if (accum_px > ctx->ws_accum_px) {
-    if (ctx->d_accum) PB_HIP(hipFree(ctx->d_accum));
-    ctx->d_accum = nullptr; ctx->ws_accum_px = 0;
-    PB_HIP(hipMalloc(&ctx->d_accum, sizeof(unsigned long long) * 3 * accum_px));
-    ctx->ws_accum_px = accum_px;
+  if (item_cap > ws.ws_item_cap) {
+    if (ws.d_items) PB_HIP(hipFree(ws.d_items));
+    ws.d_items = nullptr; ws.ws_item_cap = 0;
+    PB_HIP(hipMalloc(&ws.d_items, sizeof(uint32_t) * 4 * (size_t)item_cap));
+    ws.ws_item_cap = item_cap;
   }
+  if (accum_px > ws.ws_accum_px) {
+    if (ws.d_accum) PB_HIP(hipFree(ws.d_accum));
+    ws.d_accum = nullptr; ws.ws_accum_px = 0;
+    PB_HIP(hipMalloc(&ws.d_accum, sizeof(unsigned long long) * 3 * accum_px));
+    ws.ws_accum_px = accum_px;
+  }
+  return PB_OK;
+}
+
+int ensure_bin_mask(FrameWorkspace& ws, size_t need) {
+  if (need <= ws.ws_mask_cap) return PB_OK;
+  if (ws.fixed) return beyond_fixed("(segment, lane) binning records (8 per segment)", need, ws.ws_mask_cap);
+  if (ws.d_bin_mask) PB_HIP(hipFree(ws.d_bin_mask));
+  ws.d_bin_mask = nullptr; ws.ws_mask_cap = 0;
+  PB_HIP(hipMalloc(&ws.d_bin_mask, sizeof(unsigned long long) * need));
+  ws.ws_mask_cap = need;
   return PB_OK;
 }
 
 // Frame through screen-space bins (cull mode 2); p is complete except for the workspace pointers.
-int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long long key[6], hipStream_t s) {
+int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, const unsigned long long key[6], hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   const int groups = tiles * p.ssaa * p.ssaa;
   const size_t px = (size_t)tiles * 64;      // pixel sums are stored per tile
-  bool verified = std::memcmp(key, ctx->ws_key, sizeof(unsigned long long) * 6) == 0;
+  bool verified = std::memcmp(key, ws.ws_key, sizeof(unsigned long long) * 6) == 0;
   if (ctx->tune_slice <= 0) {
-    if (verified && ctx->ws_slice > 0) p.slice = ctx->ws_slice;
-    else if (!verified) ctx->ws_slice = 0;
+    if (verified && ws.ws_slice > 0) p.slice = ws.ws_slice;
+    else if (!verified) ws.ws_slice = 0;
   }
-  int want_bins = ctx->ws_bin_cap, want_items = ctx->ws_item_cap;
+  int want_bins = ws.ws_bin_cap, want_items = ws.ws_item_cap;
   if (!verified) {
     if (want_bins < tiles * 64 + 1024) want_bins = tiles * 64 + 1024;
     if (want_items < groups * 2 + 1024) want_items = groups * 2 + 1024;
   }
   for (int attempt = 0; attempt < 4; ++attempt) {
-    int rc = ensure_workspace(ctx, groups, 0);
+    int rc = ensure_workspace(ws, groups, 0);
     if (rc != PB_OK) return rc;
     // With interleaved strips a macro tile takes fewer tile rows: eight would span strip_stride times the
     // height on screen and hand every tile the segments of a whole column to refine.
@@ -164,54 +252,49 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
     if (const char* e = std::getenv("PB_TUNE_MACROH")) { int v = std::atoi(e); if (v >= 1 && v <= PB_MACRO) p.macro_h = v; }
     const int mtiles = pb_macro_count(p);
     const int slots = mtiles * PB_MACRO * p.macro_h;     // queue slots: every macro tile has room for all its tiles
-    rc = ensure_bin_workspace(ctx, slots, want_bins, want_items, px);
+    rc = ensure_bin_workspace(ws, slots, want_bins, want_items, px);
     if (rc != PB_OK) return rc;
-    p.rays = ctx->d_rays; p.group_last = ctx->d_group_last; p.ctrl = ctx->d_ctrl;
+    p.rays = ws.d_rays; p.group_last = ws.d_group_last; p.ctrl = ws.d_ctrl;
     {
-      const size_t T = (size_t)ctx->ws_tiles;
-      p.tile_count = ctx->d_tile_u32; p.item_off = ctx->d_tile_u32 + T;
-      p.macro_cnt = ctx->d_tile_u32 + 2 * T; p.macro_rank = ctx->d_tile_u32 + 3 * T;
-      p.sub_count = ctx->d_tile_u32 + 4 * T; p.sub_fill = p.sub_count + T * PB_BIN_SUBS; p.sub_off = p.sub_fill + T * PB_BIN_SUBS;
+      const size_t T = (size_t)ws.ws_tiles;
+      p.tile_count = ws.d_tile_u32; p.item_off = ws.d_tile_u32 + T;
+      p.macro_cnt = ws.d_tile_u32 + 2 * T; p.macro_rank = ws.d_tile_u32 + 3 * T;
+      p.sub_count = ws.d_tile_u32 + 4 * T; p.sub_fill = p.sub_count + T * PB_BIN_SUBS; p.sub_off = p.sub_fill + T * PB_BIN_SUBS;
     }
-    p.bin_list = ctx->d_bin_list; p.items = ctx->d_items; p.accum = ctx->d_accum;
-    p.bin_capacity = ctx->ws_bin_cap; p.item_capacity = ctx->ws_item_cap;
+    p.bin_list = ws.d_bin_list; p.items = ws.d_items; p.accum = ws.d_accum;
+    p.bin_capacity = ws.ws_bin_cap; p.item_capacity = ws.ws_item_cap;
     p.fused_queue = (mtiles <= pb_fused_queue_macros()) ? 1 : 0;
     p.bin_mask = nullptr;
     if (p.fused_queue && p.n_seg > 0) {
-      const size_t need = (size_t)p.n_seg * PB_BIN_FAN;
-      if (need > ctx->ws_mask_cap) {
-        if (ctx->d_bin_mask) PB_HIP(hipFree(ctx->d_bin_mask));
-        ctx->d_bin_mask = nullptr; ctx->ws_mask_cap = 0;
-        PB_HIP(hipMalloc(&ctx->d_bin_mask, sizeof(unsigned long long) * need));
-        ctx->ws_mask_cap = need;
-      }
-      p.bin_mask = ctx->d_bin_mask;
+      rc = ensure_bin_mask(ws, (size_t)p.n_seg * PB_BIN_FAN);
+      if (rc != PB_OK) return rc;
+      p.bin_mask = ws.d_bin_mask;
     }
     PB_HIP(hipEventRecord(ctx->ev[0], s));
-    if (p.fused_queue && !ctx->bins_clean)
-      PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ctx->ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
-    ctx->bins_clean = false;
+    if (p.fused_queue && !ws.bins_clean)
+      PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ws.ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
+    ws.bins_clean = false;
     if (!p.fused_queue) {
       PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
-      PB_HIP(hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * 4, s));
-      PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ctx->ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
-      PB_HIP(hipMemsetAsync(ctx->d_accum, 0, sizeof(unsigned long long) * 3 * px, s));
+      PB_HIP(hipMemsetAsync(ws.d_ctrl, 0, sizeof(uint32_t) * 4, s));
+      PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ws.ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
+      PB_HIP(hipMemsetAsync(ws.d_accum, 0, sizeof(unsigned long long) * 3 * px, s));
     }
     rc = pb_launch_ray_setup(p, ctx->count_on, s);
     if (rc != PB_OK) return rc;
     rc = pb_launch_bin_count(p, ctx->count_on, s);     // count pass, then (small frames) the whole queue in one block
     if (rc != PB_OK) return rc;
     if (!p.fused_queue) {
-      rc = pb_exclusive_scan_u32(p.sub_count, p.sub_off, mtiles * PB_BIN_SUBS, ctx->d_ctrl + 2, ctx->d_scan_tmp, s);
+      rc = pb_exclusive_scan_u32(p.sub_count, p.sub_off, mtiles * PB_BIN_SUBS, ws.d_ctrl + 2, ws.d_scan_tmp, s);
       if (rc != PB_OK) return rc;
-      rc = pb_exclusive_scan_u32(p.item_off, p.item_off, slots, ctx->d_ctrl + 0, ctx->d_scan_tmp, s);
+      rc = pb_exclusive_scan_u32(p.item_off, p.item_off, slots, ws.d_ctrl + 0, ws.d_scan_tmp, s);
       if (rc != PB_OK) return rc;
     }
     if (verified) break;
-    PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+    PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ws.d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
     PB_HIP(hipStreamSynchronize(s));
     const uint32_t need_items = ctx->h_ctrl[0], need_bins = ctx->h_ctrl[2];
-    if (ctx->tune_slice <= 0 && ctx->ws_slice == 0) {
+    if (ctx->tune_slice <= 0 && ws.ws_slice == 0) {
       // Item length from the mean macro-tile list: a wave walks its item's survivors one L2 round trip after
       // the other, so a frame with short lists (few items, GPU far from full) wants short items, while long
       // lists amortise the per-item work better with longer ones.  Measured: 1052 segments 0.145 -> 0.100 ms at
@@ -226,7 +309,7 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
       if (queued) longest = longest * 3 / 2;
       const int shortest = queued ? 64 : 48;
       want = want < shortest ? shortest : (want > longest ? longest : want);
-      ctx->ws_slice = want;
+      ws.ws_slice = want;
       if (want != p.slice) {                 // same capacities, queue rebuilt with the new length
         p.slice = want;
         if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
@@ -234,30 +317,36 @@ int render_binned(pb_ctx* ctx, RenderParams& p, int mode, const unsigned long lo
         continue;
       }
     }
-    if (need_items <= (uint32_t)ctx->ws_item_cap && need_bins <= (uint32_t)ctx->ws_bin_cap) {
-      ctx->ws_items_needed = (int)need_items;
-      std::memcpy(ctx->ws_key, key, sizeof(unsigned long long) * 6);
+    if (need_items <= (uint32_t)ws.ws_item_cap && need_bins <= (uint32_t)ws.ws_bin_cap) {
+      ws.ws_items_needed = (int)need_items;
+      std::memcpy(ws.ws_key, key, sizeof(unsigned long long) * 6);
       verified = true;
       break;
     }
-    if (need_items > (uint32_t)ctx->ws_item_cap) want_items = (int)(need_items + need_items / 4 + 64);
-    if (need_bins > (uint32_t)ctx->ws_bin_cap) want_bins = (int)(need_bins + need_bins / 4 + 64);
+    if (need_items > (uint32_t)ws.ws_item_cap) want_items = (int)(need_items + need_items / 4 + 64);
+    if (need_bins > (uint32_t)ws.ws_bin_cap) want_bins = (int)(need_bins + need_bins / 4 + 64);
     if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
   }
   if (!verified) { pb_set_error("pb_render: bin workspace could not be sized"); return PB_ERR_CAPACITY; }
-  p.n_items_host = ctx->ws_items_needed;
+  p.n_items_host = ws.ws_items_needed;
   int rc = pb_launch_bin_fill_eval(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
-  ctx->bins_clean = p.fused_queue != 0;      // finalize_kernel has cleared the counters this frame used
+  ws.bins_clean = p.fused_queue != 0;      // finalize_kernel has cleared the counters this frame used
   PB_HIP(hipEventRecord(ctx->ev[1], s));
   ctx->ev_valid[0] = true;
   return PB_OK;
 }
 
-int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_stride, int mode, int use_lbvh,
+int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, int out_h, int strip_stride, int mode, int use_lbvh,
                   float* d_out, hipStream_t s) {
   if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
   if (!ctx->have_segments) { pb_set_error("pb_render: no segment set (pb_upload_segments / pb_emit_beams)"); return PB_ERR_STATE; }
+  if (ws.fixed) {
+    // shared by every context of this GPU and left as the last call left it: nothing in it is trusted to be zero,
+    // and what was verified for another context's frame says nothing about this one
+    ws.bins_clean = false;
+    if (ws.owner != ctx->id) { std::memset(ws.ws_key, 0, sizeof(ws.ws_key)); ws.ws_slice = 0; ws.owner = ctx->id; }
+  }
   if (mode == PB_MODE_DEFAULT) mode = default_mode(ctx);
   if (mode != PB_MODE_721 && mode != PB_MODE_73HET && mode != PB_MODE_73 && mode != PB_MODE_GENERIC) {
     pb_set_error("pb_render: mode must be PB_MODE_721, PB_MODE_73, PB_MODE_73HET or PB_MODE_GENERIC"); return PB_ERR_ARG;
@@ -310,26 +399,26 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
                                      (unsigned long long)strip_stride,
                                      (unsigned long long)use_lbvh,
                                      (unsigned long long)mode};
-  if (use_lbvh == 2) return render_binned(ctx, p, mode, key, s);
-  bool verified = std::memcmp(key, ctx->ws_key, sizeof(key)) == 0;
-  int want_chunks = ctx->ws_chunks;
+  if (use_lbvh == 2) return render_binned(ctx, ws, p, mode, key, s);
+  bool verified = std::memcmp(key, ws.ws_key, sizeof(key)) == 0;
+  int want_chunks = ws.ws_chunks;
   if (!verified && want_chunks < groups * 2 + 1024) want_chunks = groups * 2 + 1024;
   for (int attempt = 0; attempt < 4; ++attempt) {
-    int rc = ensure_workspace(ctx, groups, want_chunks);
+    int rc = ensure_workspace(ws, groups, want_chunks);
     if (rc != PB_OK) return rc;
-    p.rays = ctx->d_rays; p.group_last = ctx->d_group_last; p.chunks = ctx->d_chunks;
-    p.partials = ctx->d_partials; p.ctrl = ctx->d_ctrl; p.chunk_capacity = ctx->ws_chunks;
-    PB_HIP(hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * 4, s));
+    p.rays = ws.d_rays; p.group_last = ws.d_group_last; p.chunks = ws.d_chunks;
+    p.partials = ws.d_partials; p.ctrl = ws.d_ctrl; p.chunk_capacity = ws.ws_chunks;
+    PB_HIP(hipMemsetAsync(ws.d_ctrl, 0, sizeof(uint32_t) * 4, s));
     PB_HIP(hipEventRecord(ctx->ev[0], s));
     rc = pb_launch_cull(p, mode, ctx->count_on, s);
     if (rc != PB_OK) return rc;
     if (verified) break;
-    PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+    PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ws.d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
     PB_HIP(hipStreamSynchronize(s));
     const uint32_t needed = ctx->h_ctrl[0];
-    if (needed <= (uint32_t)ctx->ws_chunks) {
-      ctx->ws_items_needed = (int)needed;
-      std::memcpy(ctx->ws_key, key, sizeof(key));
+    if (needed <= (uint32_t)ws.ws_chunks) {
+      ws.ws_items_needed = (int)needed;
+      std::memcpy(ws.ws_key, key, sizeof(key));
       verified = true;
       break;
     }
@@ -337,7 +426,7 @@ int render_common(pb_ctx* ctx, int x0, int y0, int out_w, int out_h, int strip_s
     if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
   }
   if (!verified) { pb_set_error("pb_render: candidate chunk pool could not be sized"); return PB_ERR_CAPACITY; }
-  p.n_items_host = ctx->ws_items_needed;
+  p.n_items_host = ws.ws_items_needed;
   int rc = pb_launch_eval_reduce(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
   PB_HIP(hipEventRecord(ctx->ev[1], s));
@@ -383,6 +472,7 @@ int pb_create(const pb_control* control, int device, pb_ctx** out) {
   pb_ctx* ctx = new pb_ctx();
   ctx->ctl = *control;
   ctx->device = device;
+  { static std::mutex mu; static unsigned long long next_id = 0; std::lock_guard<std::mutex> lock(mu); ctx->id = ++next_id; }
   std::memset(&ctx->stats, 0, sizeof(ctx->stats));
   *out = nullptr;
   auto set_up = [&]() -> int {
@@ -392,7 +482,8 @@ int pb_create(const pb_control* control, int device, pb_ctx** out) {
     PB_HIP(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * PB_CNT_N));
     PB_HIP(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N));
     PB_HIP(hipMalloc(&ctx->d_matrix, sizeof(float) * 16));
-    PB_HIP(hipMalloc(&ctx->d_ctrl, sizeof(uint32_t) * 4));
+    PB_HIP(hipMalloc(&ctx->ws.d_ctrl, sizeof(uint32_t) * 4));
+    { const int rc_static = static_workspace_init(device); if (rc_static != PB_OK) return rc_static; }
     PB_HIP(hipHostMalloc(&ctx->h_ctrl, sizeof(uint32_t) * 4));
     return PB_OK;
   };
@@ -410,9 +501,9 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
                   ctx->d_het, ctx->d_het_axis, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
-                  ctx->d_emit_tmp[1], ctx->d_rays, ctx->d_group_last,
-                  ctx->d_chunks, ctx->d_partials, ctx->d_ctrl, ctx->d_tile_u32, ctx->d_bin_list, ctx->d_bin_mask, ctx->d_items, ctx->d_accum,
-                  ctx->d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
+                  ctx->d_emit_tmp[1], ctx->ws.d_rays, ctx->ws.d_group_last,
+                  ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list, ctx->ws.d_bin_mask,
+                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
                   ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
@@ -625,7 +716,30 @@ int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbv
   if (x0 + w > ctx->ctl.screen_width || y0 + h > ctx->ctl.screen_height) { pb_set_error("pb_render: rectangle exceeds the screen"); return PB_ERR_ARG; }
   int rc = ensure_device(ctx);
   if (rc != PB_OK) return rc;
-  return render_common(ctx, x0, y0, w, h, 1, mode, use_lbvh, d_rgb_out, (hipStream_t)stream);
+  return render_common(ctx, ctx->ws, x0, y0, w, h, 1, mode, use_lbvh, d_rgb_out, (hipStream_t)stream);
+}
+
+int pb_render_noalloc_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, float* d_rgb_out, void* stream) {
+  if (!ctx || !d_rgb_out || w <= 0 || h <= 0 || x0 < 0 || y0 < 0) { pb_set_error("pb_render_noalloc_d: bad argument"); return PB_ERR_ARG; }
+  if (x0 + w > ctx->ctl.screen_width || y0 + h > ctx->ctl.screen_height) { pb_set_error("pb_render_noalloc_d: rectangle exceeds the screen"); return PB_ERR_ARG; }
+  int rc = ensure_device(ctx);
+  if (rc != PB_OK) return rc;
+  if (ctx->device < 0 || ctx->device >= MAX_DEVICES || !g_static[ctx->device].base) {
+    pb_set_error("pb_render_noalloc_d: the static workspace of this GPU was not set up by pb_create"); return PB_ERR_STATE;
+  }
+  // sizes are checked against the stated maxima before anything is launched
+  const long long groups = (long long)((w + 7) / 8) * ((h + 7) / 8) * ctx->ctl.ssaa * ctx->ctl.ssaa;
+  if (groups > PB_NOALLOC_MAX_GROUPS) {
+    pb_set_error("pb_render_noalloc_d: " + std::to_string(groups) + " ray groups (8x8-pixel tiles x SSAA^2) exceed PB_NOALLOC_MAX_GROUPS = " +
+                 std::to_string(PB_NOALLOC_MAX_GROUPS));
+    return PB_ERR_CAPACITY;
+  }
+  if (ctx->n_seg > PB_NOALLOC_MAX_SEGMENTS) {
+    pb_set_error("pb_render_noalloc_d: " + std::to_string(ctx->n_seg) + " segments exceed PB_NOALLOC_MAX_SEGMENTS = " +
+                 std::to_string(PB_NOALLOC_MAX_SEGMENTS));
+    return PB_ERR_CAPACITY;
+  }
+  return render_common(ctx, g_static[ctx->device].ws, x0, y0, w, h, 1, mode, 2, d_rgb_out, (hipStream_t)stream);
 }
 
 int pb_render(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh, float* rgb_out) {
@@ -653,7 +767,7 @@ int pb_render_strips_d(pb_ctx* ctx, int first_strip, int strip_stride, int n_str
   if (last_y >= ctx->ctl.screen_height) { pb_set_error("pb_render_strips_d: strips exceed the screen"); return PB_ERR_ARG; }
   int rc = ensure_device(ctx);
   if (rc != PB_OK) return rc;
-  return render_common(ctx, 0, 8 * first_strip, ctx->ctl.screen_width, 8 * n_strips, strip_stride, mode, use_lbvh,
+  return render_common(ctx, ctx->ws, 0, 8 * first_strip, ctx->ctl.screen_width, 8 * n_strips, strip_stride, mode, use_lbvh,
                        d_rgb_out, (hipStream_t)stream);
 }
 

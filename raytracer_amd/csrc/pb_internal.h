@@ -183,6 +183,32 @@ enum { PB_CNT_RAYS = 0, PB_CNT_RAYS_HIT, PB_CNT_CAND, PB_CNT_CYL, PB_CNT_VALID, 
        // queue empty (both stored as ~t so that atomicMax yields the minimum), last wave end; items processed
        PB_CNT_T_START_INV, PB_CNT_T_DRAIN_INV, PB_CNT_T_END, PB_CNT_ITEMS, PB_CNT_N };
 
+// Device memory one frame works in besides its inputs and its output (see pb_render.hip).  A context owns one
+// that grows on demand (hipMalloc); pb_render_noalloc_d uses one of fixed capacities laid out in a file-scope
+// device array, shared by every context on that GPU.
+struct FrameWorkspace {
+  bool fixed = false;                  // capacities cannot grow: a need beyond them is PB_ERR_CAPACITY
+  float* d_rays = nullptr;
+  int* d_group_last = nullptr;
+  uint32_t* d_chunks = nullptr;
+  double* d_partials = nullptr;
+  uint32_t* d_ctrl = nullptr;          // 4 control words (items / chunks produced, list entries)
+  int ws_groups = 0, ws_chunks = 0;
+  uint32_t* d_tile_u32 = nullptr;      // tile_count | item_off | macro_cnt | macro_rank (ws_tiles each) | sub_count | sub_fill | sub_off
+  uint32_t* d_bin_list = nullptr;
+  unsigned long long* d_bin_mask = nullptr;   // the counting pass's findings per (segment, lane), for the filling pass
+  size_t ws_mask_cap = 0;
+  uint32_t* d_items = nullptr;
+  unsigned long long* d_accum = nullptr;
+  uint32_t* d_scan_tmp = nullptr;
+  int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_items_needed = 0;
+  size_t ws_accum_px = 0;
+  bool bins_clean = false;   // every bin counter is zero (left so by the last frame's finalize_kernel)
+  unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // segment set + frame geometry the capacities were verified for
+  unsigned long long owner = 0;        // id of the context whose frame ws_key describes (fixed workspaces are shared)
+  int ws_slice = 0;                    // item length chosen for the frame geometry of ws_key (0: not chosen yet)
+};
+
 void pb_set_error(const std::string& msg);
 
 // One GPU's state (opaque to callers of the C ABI).
@@ -218,7 +244,6 @@ struct pb_ctx {
   int grid_side = 0;
   int grid_fast_div = 0;   // the cell size passed pb_set_grid's division check (GridView::fast_div)
   int n_seg = 0, cap_seg = 0, frame_mode = 0;
-  bool bins_clean = false;   // every bin counter of the workspace is zero (left so by the last frame's finalize_kernel)
   bool have_segments = false;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   // output staging for the host-pointer render
@@ -236,30 +261,15 @@ struct pb_ctx {
   float* lb_leaf_box = nullptr;
   int lb_n = -1;
   unsigned long long lb_version = ~0ull;
-  // frame workspace
-  float* d_rays = nullptr;
-  int* d_group_last = nullptr;
-  uint32_t* d_chunks = nullptr;
-  double* d_partials = nullptr;
-  uint32_t* d_ctrl = nullptr;
-  uint32_t* h_ctrl = nullptr;          // pinned
-  int ws_groups = 0, ws_chunks = 0;
-  uint32_t* d_tile_u32 = nullptr;      // tile_count | item_off | macro_cnt | macro_rank (ws_tiles each) | sub_count | sub_fill | sub_off
-  uint32_t* d_bin_list = nullptr;
-  unsigned long long* d_bin_mask = nullptr;   // the counting pass's findings per (segment, lane), for the filling pass
-  size_t ws_mask_cap = 0;
-  uint32_t* d_items = nullptr;
-  unsigned long long* d_accum = nullptr;
-  uint32_t* d_scan_tmp = nullptr;
-  int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_scan_words = 0, ws_items_needed = 0;
-  size_t ws_accum_px = 0;
+  // frame workspace: grown on demand by this context's render calls
+  FrameWorkspace ws;
+  uint32_t* h_ctrl = nullptr;          // pinned copy of the workspace's control words
+  unsigned long long id = 0;           // unique per created context (a freed context's address may be handed out again)
   unsigned long long segs_version = 0; // bumped whenever the segment set or scene changes
-  unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // frame geometry the chunk capacity was verified for
   // counters
   unsigned long long* d_counters = nullptr;
   bool count_on = false;
   bool precise = false;
-  int ws_slice = 0;                       // item length chosen for the frame geometry of ws_key (0: not chosen yet)
   int tune_slice = 0, tune_waves = 0;     // 0: defaults chosen per frame   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
   pb_stats stats;
 };
