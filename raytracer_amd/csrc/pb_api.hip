@@ -51,8 +51,7 @@ constexpr size_t SCRATCH_GROUP_LAST = SCRATCH_RAYS + align256(sizeof(float) * PB
 constexpr size_t SCRATCH_TILE_U32 = SCRATCH_GROUP_LAST + align256(sizeof(int) * (size_t)PB_NOALLOC_MAX_GROUPS);
 constexpr size_t SCRATCH_SCAN_TMP = SCRATCH_TILE_U32 + align256(sizeof(uint32_t) * (4 + 3 * (size_t)PB_BIN_SUBS) * NOALLOC_SLOTS);
 constexpr size_t SCRATCH_BIN_LIST = SCRATCH_SCAN_TMP + align256(sizeof(uint32_t) * (NOALLOC_SLOTS * PB_BIN_SUBS / 256 + 64));
-constexpr size_t SCRATCH_BIN_MASK = SCRATCH_BIN_LIST + align256(sizeof(uint32_t) * (size_t)PB_NOALLOC_MAX_LIST_ENTRIES);
-constexpr size_t SCRATCH_ITEMS = SCRATCH_BIN_MASK + align256(sizeof(unsigned long long) * PB_BIN_FAN * (size_t)PB_NOALLOC_MAX_SEGMENTS);
+constexpr size_t SCRATCH_ITEMS = SCRATCH_BIN_LIST + align256(sizeof(uint32_t) * (size_t)PB_NOALLOC_MAX_LIST_ENTRIES);
 constexpr size_t SCRATCH_ACCUM = SCRATCH_ITEMS + align256(sizeof(uint32_t) * 4 * (size_t)PB_NOALLOC_MAX_ITEMS);
 constexpr size_t SCRATCH_BYTES = SCRATCH_ACCUM + align256(sizeof(unsigned long long) * 3 * 64 * (size_t)PB_NOALLOC_MAX_GROUPS);
 static_assert(SCRATCH_BYTES <= (size_t)PB_NOALLOC_SCRATCH_BYTES, "the layout must fit the stated size of the static workspace");
@@ -86,8 +85,6 @@ int static_workspace_init(int device) {
   ws.ws_tiles = (int)NOALLOC_SLOTS;
   ws.d_bin_list = (uint32_t*)(b + SCRATCH_BIN_LIST);
   ws.ws_bin_cap = PB_NOALLOC_MAX_LIST_ENTRIES;
-  ws.d_bin_mask = (unsigned long long*)(b + SCRATCH_BIN_MASK);
-  ws.ws_mask_cap = (size_t)PB_BIN_FAN * PB_NOALLOC_MAX_SEGMENTS;
   ws.d_items = (uint32_t*)(b + SCRATCH_ITEMS);
   ws.ws_item_cap = PB_NOALLOC_MAX_ITEMS;
   ws.d_accum = (unsigned long long*)(b + SCRATCH_ACCUM);
@@ -217,22 +214,13 @@ int ensure_bin_workspace(FrameWorkspace& ws, int tiles, int bin_cap, int item_ca
   return PB_OK;
 }
 
-int ensure_bin_mask(FrameWorkspace& ws, size_t need) {
-  if (need <= ws.ws_mask_cap) return PB_OK;
-  if (ws.fixed) return beyond_fixed("(segment, lane) binning records (8 per segment)", need, ws.ws_mask_cap);
-  if (ws.d_bin_mask) PB_HIP(hipFree(ws.d_bin_mask));
-  ws.d_bin_mask = nullptr; ws.ws_mask_cap = 0;
-  PB_HIP(hipMalloc(&ws.d_bin_mask, sizeof(unsigned long long) * need));
-  ws.ws_mask_cap = need;
-  return PB_OK;
-}
-
 // Frame through screen-space bins (cull mode 2); p is complete except for the workspace pointers.
 int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, const unsigned long long key[6], hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   const int groups = tiles * p.ssaa * p.ssaa;
   const size_t px = (size_t)tiles * 64;      // pixel sums are stored per tile
   bool verified = std::memcmp(key, ws.ws_key, sizeof(unsigned long long) * 6) == 0;
+  if (!verified) ws.queue_kept = false;
   if (ctx->tune_slice <= 0) {
     if (verified && ws.ws_slice > 0) p.slice = ws.ws_slice;
     else if (!verified) ws.ws_slice = 0;
@@ -265,15 +253,21 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     p.bin_capacity = ws.ws_bin_cap; p.item_capacity = ws.ws_item_cap;
     p.fused_queue = (mtiles <= pb_fused_queue_macros()) ? 1 : 0;
     p.bin_mask = nullptr;
-    if (p.fused_queue && p.n_seg > 0) {
-      rc = ensure_bin_mask(ws, (size_t)p.n_seg * PB_BIN_FAN);
-      if (rc != PB_OK) return rc;
-      p.bin_mask = ws.d_bin_mask;
-    }
     PB_HIP(hipEventRecord(ctx->ev[0], s));
     if (p.fused_queue && !ws.bins_clean)
       PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ws.ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
     ws.bins_clean = false;
+    if (verified && ws.queue_kept && p.fused_queue && !ctx->count_on && p.n_seg > 0) {
+      // The list offsets and the item queue are functions of the segment set and the frame geometry alone and are in
+      // the workspace from the frame that sized it for this key: ray set-up + the fill of the lists, evaluation, pixels.
+      p.n_items_host = ws.ws_items_needed;
+      rc = pb_launch_fast_frame(p, mode, s);
+      if (rc != PB_OK) return rc;
+      ws.bins_clean = true;
+      PB_HIP(hipEventRecord(ctx->ev[1], s));
+      ctx->ev_valid[0] = true;
+      return PB_OK;
+    }
     if (!p.fused_queue) {
       PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
       PB_HIP(hipMemsetAsync(ws.d_ctrl, 0, sizeof(uint32_t) * 4, s));
@@ -332,6 +326,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
   int rc = pb_launch_bin_fill_eval(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
   ws.bins_clean = p.fused_queue != 0;      // finalize_kernel has cleared the counters this frame used
+  ws.queue_kept = p.fused_queue != 0 && p.n_seg > 0;
   PB_HIP(hipEventRecord(ctx->ev[1], s));
   ctx->ev_valid[0] = true;
   return PB_OK;
@@ -345,7 +340,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
     // shared by every context of this GPU and left as the last call left it: nothing in it is trusted to be zero,
     // and what was verified for another context's frame says nothing about this one
     ws.bins_clean = false;
-    if (ws.owner != ctx->id) { std::memset(ws.ws_key, 0, sizeof(ws.ws_key)); ws.ws_slice = 0; ws.owner = ctx->id; }
+    if (ws.owner != ctx->id) { std::memset(ws.ws_key, 0, sizeof(ws.ws_key)); ws.ws_slice = 0; ws.queue_kept = false; ws.owner = ctx->id; }
   }
   if (mode == PB_MODE_DEFAULT) mode = default_mode(ctx);
   if (mode != PB_MODE_721 && mode != PB_MODE_73HET && mode != PB_MODE_73 && mode != PB_MODE_GENERIC) {
@@ -418,6 +413,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
     const uint32_t needed = ctx->h_ctrl[0];
     if (needed <= (uint32_t)ws.ws_chunks) {
       ws.ws_items_needed = (int)needed;
+      ws.queue_kept = false;
       std::memcpy(ws.ws_key, key, sizeof(key));
       verified = true;
       break;
@@ -502,7 +498,7 @@ void pb_destroy(pb_ctx* ctx) {
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
                   ctx->d_het, ctx->d_het_axis, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
                   ctx->d_emit_tmp[1], ctx->ws.d_rays, ctx->ws.d_group_last,
-                  ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list, ctx->ws.d_bin_mask,
+                  ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list,
                   ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
                   ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -732,11 +728,6 @@ int pb_render_noalloc_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, flo
   if (groups > PB_NOALLOC_MAX_GROUPS) {
     pb_set_error("pb_render_noalloc_d: " + std::to_string(groups) + " ray groups (8x8-pixel tiles x SSAA^2) exceed PB_NOALLOC_MAX_GROUPS = " +
                  std::to_string(PB_NOALLOC_MAX_GROUPS));
-    return PB_ERR_CAPACITY;
-  }
-  if (ctx->n_seg > PB_NOALLOC_MAX_SEGMENTS) {
-    pb_set_error("pb_render_noalloc_d: " + std::to_string(ctx->n_seg) + " segments exceed PB_NOALLOC_MAX_SEGMENTS = " +
-                 std::to_string(PB_NOALLOC_MAX_SEGMENTS));
     return PB_ERR_CAPACITY;
   }
   return render_common(ctx, g_static[ctx->device].ws, x0, y0, w, h, 1, mode, 2, d_rgb_out, (hipStream_t)stream);

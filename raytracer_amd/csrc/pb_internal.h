@@ -196,8 +196,6 @@ struct FrameWorkspace {
   int ws_groups = 0, ws_chunks = 0;
   uint32_t* d_tile_u32 = nullptr;      // tile_count | item_off | macro_cnt | macro_rank (ws_tiles each) | sub_count | sub_fill | sub_off
   uint32_t* d_bin_list = nullptr;
-  unsigned long long* d_bin_mask = nullptr;   // the counting pass's findings per (segment, lane), for the filling pass
-  size_t ws_mask_cap = 0;
   uint32_t* d_items = nullptr;
   unsigned long long* d_accum = nullptr;
   uint32_t* d_scan_tmp = nullptr;
@@ -207,6 +205,7 @@ struct FrameWorkspace {
   unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // segment set + frame geometry the capacities were verified for
   unsigned long long owner = 0;        // id of the context whose frame ws_key describes (fixed workspaces are shared)
   int ws_slice = 0;                    // item length chosen for the frame geometry of ws_key (0: not chosen yet)
+  bool queue_kept = false;             // list offsets and item queue of ws_key's frame are in place (fused queue only)
 };
 
 void pb_set_error(const std::string& msg);
@@ -305,5 +304,6 @@ PB_HDI int pb_macro_count(const RenderParams& p) {
   return ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
 }
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s);
+int pb_launch_fast_frame(const RenderParams& p, int mode, hipStream_t s);
 
 #endif

@@ -751,6 +751,97 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const RenderParams p, 
   bin_body<FILL, LDS>(p, n_macro, bin_lds, blockIdx.x);
 }
 
+// Binning of frames with at most QUEUE_FUSED_MACROS macro tiles: lane = macro tile.  A wave takes `spw`
+// consecutive segments (one per lane, handed round with v_readlane) and every lane clips each of them against
+// the pyramid of its own macro tile, whose planes it sets up once: no walk over a segment's tiles, no
+// dependent memory access per segment, and a segment's incidences with all macro tiles cost one pass of about
+// sixty instructions.  What a lane found is a bit mask over the wave's segments, so positions inside a list follow
+// from bit counts: per (wave, macro tile) counts go to LDS, one thread per macro tile turns them into the waves'
+// offsets and reserves the block's range with ONE global atomic (same-address device atomics run at about 12 ns
+// each), and the fill pass then writes every lane's segments in ascending order.  COUNT pass: only the totals.
+// The fill pass of a frame whose list offsets are already known (sub_off kept from the frame that sized the
+// workspace for this segment set and frame geometry) needs no count pass before it.
+constexpr int MBIN_THREADS = 1024;
+constexpr int MBIN_WAVES = MBIN_THREADS / 64;
+constexpr int MBIN_CHUNKS = 4;            // 64 macro tiles per chunk: QUEUE_FUSED_MACROS = 256
+PB_DI float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+PB_HDI int pb_mbin_spw(int n_seg) { return n_seg <= 4096 ? 4 : (n_seg <= 32768 ? 16 : 32); }
+PB_HDI int pb_mbin_blocks(int n_seg) { const int per = MBIN_WAVES * pb_mbin_spw(n_seg); return (n_seg + per - 1) / per; }
+PB_HDI size_t pb_mbin_lds_bytes(int n_macro) { return sizeof(uint32_t) * (size_t)(MBIN_WAVES + 1) * (size_t)n_macro; }
+
+template <bool FILL>
+PB_DI void macro_bin_body(const RenderParams& p, int n_macro, uint32_t* lds, int block) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* lwave = lds;                               // [MBIN_WAVES][n_macro] counts, then offsets inside the block's range
+  uint32_t* lbase = lds + MBIN_WAVES * n_macro;        // [n_macro] start of the block's range in bin_list
+  const int spw = pb_mbin_spw(p.n_seg);
+  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
+  const int seg0 = (block * MBIN_WAVES + wave) * spw;
+  int n_here = p.n_seg - seg0;
+  n_here = n_here < 0 ? 0 : (n_here > spw ? spw : n_here);
+  float4 A = make_float4(0, 0, 1, 0), B = A;
+  if (lane < n_here) { A = p.capA[seg0 + lane]; B = p.capB[seg0 + lane]; }
+  uint32_t masks[MBIN_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < MBIN_CHUNKS; ++c) {
+    masks[c] = 0u;
+    if (c * 64 < n_macro) {
+      const int m_raw = c * 64 + lane;
+      const int m = m_raw < n_macro ? m_raw : n_macro - 1;
+      const int my = m / mtx, mx = m % mtx;
+      // pixel rectangle of macro tile (mx, my); with interleaved strips its tile rows are strip_stride apart and the
+      // pyramid also spans the rows in between: conservative
+      const int tx0 = mx * PB_MACRO, tk0 = my * p.macro_h;
+      int tx1 = tx0 + PB_MACRO - 1, tk1 = tk0 + p.macro_h - 1;
+      if (tx1 > p.tiles_x - 1) tx1 = p.tiles_x - 1;
+      if (tk1 > p.tiles_y - 1) tk1 = p.tiles_y - 1;
+      V3 pl[4];
+      pixel_rect_planes(p, p.x0 + 8 * tx0, p.x0 + 8 * tx1 + 7, p.y0 + 8 * tk0 * p.strip_stride, p.y0 + 8 * tk1 * p.strip_stride + 7, pl);
+      uint32_t mask = 0u;
+      for (int j = 0; j < n_here; ++j) {
+        const float4 a = make_float4(readlane_f(A.x, j), readlane_f(A.y, j), readlane_f(A.z, j), readlane_f(A.w, j));
+        const float4 b = make_float4(readlane_f(B.x, j), readlane_f(B.y, j), readlane_f(B.z, j), 0.0f);
+        mask |= axis_touches_pyramid(a, b, pl) ? (1u << j) : 0u;
+      }
+      if (m_raw >= n_macro) mask = 0u;
+      masks[c] = mask;
+      if (m_raw < n_macro) lwave[wave * n_macro + m_raw] = (uint32_t)__builtin_popcount(mask);
+    }
+  }
+  __syncthreads();
+  for (int m = tid; m < n_macro; m += MBIN_THREADS) {
+    uint32_t run = 0;
+    for (int w = 0; w < MBIN_WAVES; ++w) { const uint32_t c = lwave[w * n_macro + m]; lwave[w * n_macro + m] = run; run += c; }
+    if (run) {
+      if (FILL) lbase[m] = p.sub_off[m] + atomicAdd(&p.sub_fill[m], run);
+      else atomicAdd(&p.sub_count[m], run);
+    }
+  }
+  if (!FILL) return;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < MBIN_CHUNKS; ++c) {
+    uint32_t mask = masks[c];
+    if (mask) {
+      const int m = c * 64 + lane;
+      uint32_t at = lbase[m] + lwave[wave * n_macro + m];
+      while (mask) {
+        const int j = __builtin_ctz(mask);
+        mask &= mask - 1;
+        if (at < (uint32_t)p.bin_capacity) p.bin_list[at] = (uint32_t)(seg0 + j);
+        ++at;
+      }
+    }
+  }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(MBIN_THREADS) void macro_bin_kernel(const RenderParams p, int n_macro) {
+  extern __shared__ uint32_t bin_lds[];
+  macro_bin_body<FILL>(p, n_macro, bin_lds, blockIdx.x);
+}
+
 // Length of every macro tile's list (sum of its sub-counters).
 __global__ __launch_bounds__(256) void macro_count_kernel(const RenderParams p, int n_macro) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -829,14 +920,23 @@ __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, i
 constexpr int ITEM_LANES = 64;
 __global__ __launch_bounds__(BIN_THREADS) void setup_count_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups) {
   extern __shared__ uint32_t bin_lds[];
-  if ((int)blockIdx.x < bin_blocks) { bin_body<false, true>(p, n_macro, bin_lds, blockIdx.x); return; }
+  if ((int)blockIdx.x < bin_blocks) { macro_bin_body<false>(p, n_macro, bin_lds, blockIdx.x); return; }
+  const int group = ((int)blockIdx.x - bin_blocks) * (BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
+  if (group < groups) ray_setup_body<false>(p, group, threadIdx.x & 63);
+}
+
+// A frame whose list offsets and evaluation items are in place (kept from the frame that sized the workspace for this
+// segment set and frame geometry): ray set-up beside the one binning pass it needs, the fill.
+__global__ __launch_bounds__(BIN_THREADS) void setup_fill_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups) {
+  extern __shared__ uint32_t bin_lds[];
+  if ((int)blockIdx.x < bin_blocks) { macro_bin_body<true>(p, n_macro, bin_lds, blockIdx.x); return; }
   const int group = ((int)blockIdx.x - bin_blocks) * (BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
   if (group < groups) ray_setup_body<false>(p, group, threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void fill_items_kernel(const RenderParams p, int n_macro, int bin_blocks, int n_tiles) {
   extern __shared__ uint32_t bin_lds[];
-  if ((int)blockIdx.x < bin_blocks) { bin_body<true, true>(p, n_macro, bin_lds, blockIdx.x); return; }
+  if ((int)blockIdx.x < bin_blocks) { macro_bin_body<true>(p, n_macro, bin_lds, blockIdx.x); return; }
   // one wave per block writes items: spread over many compute units, the scattered 16-byte stores of four
   // full blocks took as long as the whole binning pass
   if (threadIdx.x < ITEM_LANES) make_items_body(p, n_tiles, ((int)blockIdx.x - bin_blocks) * ITEM_LANES + (int)threadIdx.x);
@@ -1255,9 +1355,9 @@ int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
   if (groups <= 0) return PB_OK;
   if (shares_launches(p, count)) {
     const int n_macro = pb_macro_count(p);
-    const int bin_blocks = (int)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
+    const int bin_blocks = pb_mbin_blocks(p.n_seg);
     const int ray_blocks = (groups + BIN_THREADS / 64 - 1) / (BIN_THREADS / 64);
-    hipLaunchKernelGGL(setup_count_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s,
+    hipLaunchKernelGGL(setup_count_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), pb_mbin_lds_bytes(n_macro), s,
                        p, n_macro, bin_blocks, groups);
     PB_HIP(hipGetLastError());
     return PB_OK;
@@ -1268,18 +1368,27 @@ int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
   return PB_OK;
 }
 
+// One binning pass on its own: lane = macro tile for frames whose queue one block builds, the walk over each
+// segment's rectangle of macro tiles otherwise.
+template <bool FILL>
+static void launch_bin_pass(const RenderParams& p, int n_macro, hipStream_t s) {
+  if (p.fused_queue) {
+    hipLaunchKernelGGL(macro_bin_kernel<FILL>, dim3(pb_mbin_blocks(p.n_seg)), dim3(MBIN_THREADS), pb_mbin_lds_bytes(n_macro), s, p, n_macro);
+    return;
+  }
+  const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
+  if (n_macro <= BIN_LDS_MACROS)
+    hipLaunchKernelGGL((bin_kernel<FILL, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);
+  else hipLaunchKernelGGL((bin_kernel<FILL, false>), dim3(blocks), dim3(BIN_THREADS), 0, s, p, n_macro);
+}
+
 // count pass, then the two prefix sums (entries per tile -> tile_off, ctrl[2] = total entries;
 // items per tile -> item_off, ctrl[0] = total items)
 int pb_launch_bin_count(const RenderParams& p, bool count, hipStream_t s) {
   const int tiles = p.tiles_x * p.tiles_y;
   if (tiles <= 0) return PB_OK;
   const int n_macro = pb_macro_count(p);
-  if (p.n_seg > 0 && !shares_launches(p, count)) {
-    const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
-    if (n_macro <= BIN_LDS_MACROS)
-      hipLaunchKernelGGL((bin_kernel<false, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);
-    else hipLaunchKernelGGL((bin_kernel<false, false>), dim3(blocks), dim3(BIN_THREADS), 0, s, p, n_macro);
-  }
+  if (p.n_seg > 0 && !shares_launches(p, count)) launch_bin_pass<false>(p, n_macro, s);
   if (p.fused_queue) {
     hipLaunchKernelGGL(queue_build_kernel, dim3(1), dim3(QUEUE_THREADS), 0, s, p, n_macro);
   } else {
@@ -1291,25 +1400,8 @@ int pb_launch_bin_count(const RenderParams& p, bool count, hipStream_t s) {
   return PB_OK;
 }
 
-int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s) {
-  const int tiles = p.tiles_x * p.tiles_y;
-  if (tiles <= 0) return PB_OK;
-  if (shares_launches(p, count)) {
-    const int n_macro = pb_macro_count(p);
-    const int bin_blocks = (int)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
-    const int item_blocks = (tiles + ITEM_LANES - 1) / ITEM_LANES;
-    hipLaunchKernelGGL(fill_items_kernel, dim3(bin_blocks + item_blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s,
-                       p, n_macro, bin_blocks, tiles);
-  } else {
-    if (p.n_seg > 0) {
-      const int n_macro = pb_macro_count(p);
-      const unsigned blocks = (unsigned)(((size_t)p.n_seg * PB_BIN_FAN + BIN_THREADS - 1) / BIN_THREADS);
-      if (n_macro <= BIN_LDS_MACROS)
-        hipLaunchKernelGGL((bin_kernel<true, true>), dim3(blocks), dim3(BIN_THREADS), sizeof(uint32_t) * 2 * n_macro, s, p, n_macro);
-      else hipLaunchKernelGGL((bin_kernel<true, false>), dim3(blocks), dim3(BIN_THREADS), 0, s, p, n_macro);
-    }
-    hipLaunchKernelGGL(make_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
-  }
+// The evaluation kernel of `mode` over the item queue, then the pixel write-out.
+static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hipStream_t s) {
   // one wave per item when PB_TUNE_WAVES=0: the hardware dispatcher then hands out the queue in order
   int waves = p.eval_waves > 0 ? p.eval_waves : p.n_items_host;
   if (waves > p.item_capacity) waves = p.item_capacity;
@@ -1330,6 +1422,35 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, p);
   PB_HIP(hipGetLastError());
   return PB_OK;
+}
+
+int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s) {
+  const int tiles = p.tiles_x * p.tiles_y;
+  if (tiles <= 0) return PB_OK;
+  if (shares_launches(p, count)) {
+    const int n_macro = pb_macro_count(p);
+    const int bin_blocks = pb_mbin_blocks(p.n_seg);
+    const int item_blocks = (tiles + ITEM_LANES - 1) / ITEM_LANES;
+    hipLaunchKernelGGL(fill_items_kernel, dim3(bin_blocks + item_blocks), dim3(BIN_THREADS), pb_mbin_lds_bytes(n_macro), s,
+                       p, n_macro, bin_blocks, tiles);
+  } else {
+    if (p.n_seg > 0) launch_bin_pass<true>(p, pb_macro_count(p), s);
+    hipLaunchKernelGGL(make_items_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles);
+  }
+  return launch_eval_finalize(p, mode, count, s);
+}
+
+// A frame whose list offsets (sub_off), item queue (items, ctrl[0]) and per-tile list lengths are in the workspace
+// from the frame that sized it for the same segment set and frame geometry: three launches.
+int pb_launch_fast_frame(const RenderParams& p, int mode, hipStream_t s) {
+  const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
+  if (groups <= 0) return PB_OK;
+  const int n_macro = pb_macro_count(p);
+  const int bin_blocks = pb_mbin_blocks(p.n_seg);
+  const int ray_blocks = (groups + BIN_THREADS / 64 - 1) / (BIN_THREADS / 64);
+  hipLaunchKernelGGL(setup_fill_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), pb_mbin_lds_bytes(n_macro), s,
+                     p, n_macro, bin_blocks, groups);
+  return launch_eval_finalize(p, mode, false, s);
 }
 
 int pb_launch_beam_axis(const float4* d_capA, const float4* d_capB, const HetFrame* d_het, int n, BeamAxis* d_out, hipStream_t s) {
