@@ -51,7 +51,9 @@ constexpr size_t SCRATCH_GROUP_LAST = SCRATCH_RAYS + align256(sizeof(float) * PB
 constexpr size_t SCRATCH_TILE_U32 = SCRATCH_GROUP_LAST + align256(sizeof(int) * (size_t)PB_NOALLOC_MAX_GROUPS);
 constexpr size_t SCRATCH_SCAN_TMP = SCRATCH_TILE_U32 + align256(sizeof(uint32_t) * (4 + 3 * (size_t)PB_BIN_SUBS) * NOALLOC_SLOTS);
 constexpr size_t SCRATCH_BIN_LIST = SCRATCH_SCAN_TMP + align256(sizeof(uint32_t) * (NOALLOC_SLOTS * PB_BIN_SUBS / 256 + 64));
-constexpr size_t SCRATCH_ITEMS = SCRATCH_BIN_LIST + align256(sizeof(uint32_t) * (size_t)PB_NOALLOC_MAX_LIST_ENTRIES);
+constexpr size_t NOALLOC_BLK_WORDS = (size_t)1 << 18;                  // (binning block, macro tile) counters: 1 MiB
+constexpr size_t SCRATCH_BLK = SCRATCH_BIN_LIST + align256(sizeof(uint32_t) * (size_t)PB_NOALLOC_MAX_LIST_ENTRIES);
+constexpr size_t SCRATCH_ITEMS = SCRATCH_BLK + align256(sizeof(uint32_t) * NOALLOC_BLK_WORDS);
 constexpr size_t SCRATCH_ACCUM = SCRATCH_ITEMS + align256(sizeof(uint32_t) * 4 * (size_t)PB_NOALLOC_MAX_ITEMS);
 constexpr size_t SCRATCH_BYTES = SCRATCH_ACCUM + align256(sizeof(unsigned long long) * 3 * 64 * (size_t)PB_NOALLOC_MAX_GROUPS);
 static_assert(SCRATCH_BYTES <= (size_t)PB_NOALLOC_SCRATCH_BYTES, "the layout must fit the stated size of the static workspace");
@@ -85,6 +87,8 @@ int static_workspace_init(int device) {
   ws.ws_tiles = (int)NOALLOC_SLOTS;
   ws.d_bin_list = (uint32_t*)(b + SCRATCH_BIN_LIST);
   ws.ws_bin_cap = PB_NOALLOC_MAX_LIST_ENTRIES;
+  ws.d_blk = (uint32_t*)(b + SCRATCH_BLK);
+  ws.ws_blk_cap = NOALLOC_BLK_WORDS;
   ws.d_items = (uint32_t*)(b + SCRATCH_ITEMS);
   ws.ws_item_cap = PB_NOALLOC_MAX_ITEMS;
   ws.d_accum = (unsigned long long*)(b + SCRATCH_ACCUM);
@@ -188,7 +192,7 @@ int ensure_bin_workspace(FrameWorkspace& ws, int tiles, int bin_cap, int item_ca
   if (tiles > ws.ws_tiles) {
     if (ws.d_tile_u32) PB_HIP(hipFree(ws.d_tile_u32));
     if (ws.d_scan_tmp) PB_HIP(hipFree(ws.d_scan_tmp));
-    ws.d_tile_u32 = nullptr; ws.d_scan_tmp = nullptr; ws.ws_tiles = 0; ws.bins_clean = false;
+    ws.d_tile_u32 = nullptr; ws.d_scan_tmp = nullptr; ws.ws_tiles = 0;
     PB_HIP(hipMalloc(&ws.d_tile_u32, sizeof(uint32_t) * (4 + 3 * (size_t)PB_BIN_SUBS) * (size_t)tiles));   // macro tiles <= tiles
     PB_HIP(hipMalloc(&ws.d_scan_tmp, sizeof(uint32_t) * pb_scan_tmp_words(tiles * PB_BIN_SUBS)));
     ws.ws_tiles = tiles;
@@ -211,6 +215,16 @@ int ensure_bin_workspace(FrameWorkspace& ws, int tiles, int bin_cap, int item_ca
     PB_HIP(hipMalloc(&ws.d_accum, sizeof(unsigned long long) * 3 * accum_px));
     ws.ws_accum_px = accum_px;
   }
+  return PB_OK;
+}
+
+int ensure_blk(FrameWorkspace& ws, size_t need) {
+  if (need <= ws.ws_blk_cap) return PB_OK;
+  if (ws.fixed) return beyond_fixed("(binning block, macro tile) counters", need, ws.ws_blk_cap);
+  if (ws.d_blk) PB_HIP(hipFree(ws.d_blk));
+  ws.d_blk = nullptr; ws.ws_blk_cap = 0;
+  PB_HIP(hipMalloc(&ws.d_blk, sizeof(uint32_t) * need));
+  ws.ws_blk_cap = need;
   return PB_OK;
 }
 
@@ -253,17 +267,19 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     p.bin_capacity = ws.ws_bin_cap; p.item_capacity = ws.ws_item_cap;
     p.fused_queue = (mtiles <= pb_fused_queue_macros()) ? 1 : 0;
     p.bin_mask = nullptr;
+    p.blk = nullptr;
+    if (p.fused_queue && p.n_seg > 0) {
+      rc = ensure_blk(ws, (size_t)pb_mbin_blocks(p.n_seg) * (size_t)mtiles);
+      if (rc != PB_OK) return rc;
+      p.blk = ws.d_blk;
+    }
     PB_HIP(hipEventRecord(ctx->ev[0], s));
-    if (p.fused_queue && !ws.bins_clean)
-      PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ws.ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
-    ws.bins_clean = false;
     if (verified && ws.queue_kept && p.fused_queue && !ctx->count_on && p.n_seg > 0) {
       // The list offsets and the item queue are functions of the segment set and the frame geometry alone and are in
       // the workspace from the frame that sized it for this key: ray set-up + the fill of the lists, evaluation, pixels.
       p.n_items_host = ws.ws_items_needed;
       rc = pb_launch_fast_frame(p, mode, s);
       if (rc != PB_OK) return rc;
-      ws.bins_clean = true;
       PB_HIP(hipEventRecord(ctx->ev[1], s));
       ctx->ev_valid[0] = true;
       return PB_OK;
@@ -325,7 +341,6 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
   p.n_items_host = ws.ws_items_needed;
   int rc = pb_launch_bin_fill_eval(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
-  ws.bins_clean = p.fused_queue != 0;      // finalize_kernel has cleared the counters this frame used
   ws.queue_kept = p.fused_queue != 0 && p.n_seg > 0;
   PB_HIP(hipEventRecord(ctx->ev[1], s));
   ctx->ev_valid[0] = true;
@@ -337,9 +352,9 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   if (!ctx->d_tris) { pb_set_error("pb_render: pb_set_scene has not been called"); return PB_ERR_STATE; }
   if (!ctx->have_segments) { pb_set_error("pb_render: no segment set (pb_upload_segments / pb_emit_beams)"); return PB_ERR_STATE; }
   if (ws.fixed) {
-    // shared by every context of this GPU and left as the last call left it: nothing in it is trusted to be zero,
-    // and what was verified for another context's frame says nothing about this one
-    ws.bins_clean = false;
+    // shared by every context of this GPU and left as the last call left it: what was verified for another
+    // context's frame says nothing about this one (nothing in it needs to be zero when a frame starts: whatever a
+    // frame accumulates into it clears first)
     if (ws.owner != ctx->id) { std::memset(ws.ws_key, 0, sizeof(ws.ws_key)); ws.ws_slice = 0; ws.queue_kept = false; ws.owner = ctx->id; }
   }
   if (mode == PB_MODE_DEFAULT) mode = default_mode(ctx);
@@ -498,7 +513,7 @@ void pb_destroy(pb_ctx* ctx) {
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
                   ctx->d_het, ctx->d_het_axis, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
                   ctx->d_emit_tmp[1], ctx->ws.d_rays, ctx->ws.d_group_last,
-                  ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list,
+                  ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list, ctx->ws.d_blk,
                   ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
                   ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};
   for (void* p : ptrs) if (p) (void)hipFree(p);

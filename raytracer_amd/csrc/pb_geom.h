@@ -7,21 +7,19 @@
 // screen_box (optional, rays from the camera at (0,0,0) only): per triangle the bounds of x/z and y/z over
 // its vertices, widened by 1e-3.  A ray outside them cannot satisfy the barycentric tests (they hold to a
 // few 1e-6), so the triangle is skipped without evaluating it; the result is unchanged.
-PB_DI bool closest_intersection(const TriPrep* __restrict__ tris, int n_tri, V4 start, V4 dir, V4& position,
-                                float& distance, int& index, const float4* __restrict__ screen_box = nullptr,
-                                unsigned long long only = ~0ull) {
+template <class TriPtr, class BoxPtr>
+PB_DI bool closest_intersection(TriPtr tris, int n_tri, V4 start, V4 dir, V4& position,
+                                float& distance, int& index, BoxPtr screen_box, unsigned long long only = ~0ull) {
   bool found = false;
   float best = 3.402823466e+38f;   // Intersections.h:57
   int best_i = -1;
   const float ndx = -dir.x, ndy = -dir.y, ndz = -dir.z;
-  for (int i = 0; i < n_tri; ++i) {
-    // `only` (same for the whole wave): triangles 0..63 the caller has ruled out for all of its rays
-    if (i < 64 && !((only >> i) & 1ull)) continue;
+  auto test = [&](int i) {
     if (screen_box) {
-      const float4 sb = screen_box[i];
-      if (dir.x < sb.x * dir.z || dir.x > sb.y * dir.z || dir.y < sb.z * dir.z || dir.y > sb.w * dir.z) continue;
+      const float sb_x = screen_box[i].x, sb_y = screen_box[i].y, sb_z = screen_box[i].z, sb_w = screen_box[i].w;
+      if (dir.x < sb_x * dir.z || dir.x > sb_y * dir.z || dir.y < sb_z * dir.z || dir.y > sb_w * dir.z) return;
     }
-    const TriPrep& T = tris[i];
+    const auto& T = tris[i];
     const float bx = start.x - T.v0[0], by = start.y - T.v0[1], bz = start.z - T.v0[2];
     const float e1x = T.e1[0], e1y = T.e1[1], e1z = T.e1[2];
     const float e2x = T.e2[0], e2y = T.e2[1], e2z = T.e2[2];
@@ -44,11 +42,26 @@ PB_DI bool closest_intersection(const TriPrep* __restrict__ tris, int n_tri, V4 
     if (xx >= 0 && xy >= 0 && xz >= 0 && (xy + xz) < 1) {
       if (xx < best) { found = true; best = xx; best_i = i; }
     }
+  };
+  // `only` (same for the whole wave): triangles 0..63 the caller has not ruled out for all of its rays; visited in
+  // ascending order like the reference's loop (the first of two equal distances wins)
+  unsigned long long todo = only;
+  if (n_tri < 64) todo &= (1ull << n_tri) - 1ull;
+  while (todo) {
+    const int i = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    test(i);
   }
+  for (int i = 64; i < n_tri; ++i) test(i);
   distance = best;
   index = best_i;
   if (found) position = start + dir * best;
   return found;
+}
+
+template <class TriPtr>
+PB_DI bool closest_intersection(TriPtr tris, int n_tri, V4 start, V4 dir, V4& position, float& distance, int& index) {
+  return closest_intersection(tris, n_tri, start, dir, position, distance, index, (const float4*)nullptr);
 }
 
 #endif

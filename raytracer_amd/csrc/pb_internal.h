@@ -139,7 +139,9 @@ struct RenderParams {
   uint32_t* sub_fill;       // [macro tiles][PB_BIN_SUBS] fill cursors of the second binning pass
   uint32_t* sub_off;        // [macro tiles][PB_BIN_SUBS] start of each sub-list in bin_list (a macro tile's are adjacent)
   uint32_t* bin_list;       // [bin_capacity] segment indices, grouped by tile
-  unsigned long long* bin_mask;   // [n_seg][PB_BIN_FAN] what the counting pass found (bit 63: valid), or null
+  uint32_t* blk;            // [binning blocks][macro tiles] lane-per-macro-tile binning: a block's count per macro tile, turned
+                            // into the start of its range inside that macro tile's list by queue_build_kernel
+  unsigned long long* bin_mask;   // [n_seg][PB_BIN_FAN] what the counting pass of the rectangle walk found (bit 63: valid), or null
   uint32_t* items;          // [items][4]: group, start, n, 0
   uint32_t* item_off;       // [queue slots] first item of the tile in that slot (macro tiles in rank order)
   uint32_t* macro_cnt;      // [macro tiles] list length
@@ -196,12 +198,13 @@ struct FrameWorkspace {
   int ws_groups = 0, ws_chunks = 0;
   uint32_t* d_tile_u32 = nullptr;      // tile_count | item_off | macro_cnt | macro_rank (ws_tiles each) | sub_count | sub_fill | sub_off
   uint32_t* d_bin_list = nullptr;
+  uint32_t* d_blk = nullptr;           // per (binning block, macro tile) counts / range starts
+  size_t ws_blk_cap = 0;
   uint32_t* d_items = nullptr;
   unsigned long long* d_accum = nullptr;
   uint32_t* d_scan_tmp = nullptr;
   int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_items_needed = 0;
   size_t ws_accum_px = 0;
-  bool bins_clean = false;   // every bin counter is zero (left so by the last frame's finalize_kernel)
   unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // segment set + frame geometry the capacities were verified for
   unsigned long long owner = 0;        // id of the context whose frame ws_key describes (fixed workspaces are shared)
   int ws_slice = 0;                    // item length chosen for the frame geometry of ws_key (0: not chosen yet)
@@ -300,6 +303,10 @@ int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream
 int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);
 int pb_launch_bin_count(const RenderParams& p, bool count, hipStream_t s);
 int pb_fused_queue_macros(void);
+// Lane-per-macro-tile binning (pb_render.hip): segments per wave and blocks of 16 waves for a segment count.
+constexpr int PB_MBIN_WAVES = 16;
+PB_HDI int pb_mbin_spw(int n_seg) { return n_seg <= 4096 ? 4 : (n_seg <= 32768 ? 16 : 32); }
+PB_HDI int pb_mbin_blocks(int n_seg) { const int per = PB_MBIN_WAVES * pb_mbin_spw(n_seg); return (n_seg + per - 1) / per; }
 PB_HDI int pb_macro_count(const RenderParams& p) {
   return ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
 }

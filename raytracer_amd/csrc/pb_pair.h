@@ -79,7 +79,9 @@ PB_DI int box_gate_quick(const float lo[3], const float hi[3], const float cand[
 
 // Per-pixel set-up of DrawStandard, skeleton.cpp:342-350, then the root gate.
 // tri_mask (wave-uniform): triangles that can be hit by any ray of the wave, see closest_intersection.
-PB_DI Ray make_ray(const RenderParams& p, int sx, int sy, unsigned long long tri_mask = ~0ull) {
+// tris / tri_box: where the prepared triangles are read from (RenderParams' own, or a copy of them in LDS).
+template <class TriPtr, class BoxPtr>
+PB_DI Ray make_ray(const RenderParams& p, int sx, int sy, unsigned long long tri_mask, TriPtr tris, BoxPtr tri_box) {
   Ray r;
   const float x_dir = sx - ((p.width * p.ssaa) / (float)2);
   const float y_dir = sy - ((p.height * p.ssaa) / (float)2);
@@ -87,7 +89,7 @@ PB_DI Ray make_ray(const RenderParams& p, int sx, int sy, unsigned long long tri
   const V4 start = v4(0, 0, 0, 1);
   V4 pos = v4(0, 0, 0, 0);
   float dist; int idx;
-  r.active = closest_intersection(p.tris, p.n_tri, start, dir, pos, dist, idx, p.tri_box, tri_mask);
+  r.active = closest_intersection(tris, p.n_tri, start, dir, pos, dist, idx, tri_box, tri_mask);
   r.maxd = r.active ? length4(pos - start) : -1.0f;
   if (p.short_view && r.active) {
     // SHORT_VIEW (skeleton.cpp:442-449): the view ray ends at a free-flight distance drawn for it; the draw
@@ -104,6 +106,10 @@ PB_DI Ray make_ray(const RenderParams& p, int sx, int sy, unsigned long long tri
   r.dn = xyz(normalize4(dir));
   r.d1 = xyz(dir);
   return r;
+}
+
+PB_DI Ray make_ray(const RenderParams& p, int sx, int sy, unsigned long long tri_mask = ~0ull) {
+  return make_ray(p, sx, sy, tri_mask, p.tris, p.tri_box);
 }
 
 // CylIntersection (Intersections.h:29-40) of a valid hit.
@@ -418,31 +424,36 @@ PB_DI int eval_pair_generic(const SegFrame& f, const HetFrame& hf, V3 seg_start,
 //    every other segment, the exact HitBoundingBox gate runs.
 PB_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // a * b with 0 * anything = 0 (also 0 * inf and 0 * NaN)
+// The s_nop is the wait state gfx950 needs between a transcendental instruction (b is often a fresh v_rcp_f32) and
+// an ordinary vector instruction that reads its result: the compiler inserts it for instructions it emits itself
+// and does not look inside inline assembly.
 PB_DI float mul_zero_wins(float a, float b) {
   float r;
-  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  asm("s_nop 0\n\tv_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 
-// log2_scale: the integral is returned times 2^log2_scale (folded into the exponential at no cost).
-template <bool CHECK>
-PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong,
-                             float log2_scale = 0.0f) {
+// The part of the fast evaluation that reads only what HitCylinder derives from the segment (the first sixteen
+// dwords of its record) and the ray: 0 = no cylinder hit, 1 = nothing to integrate, 2 = a valid crossing whose
+// entry distance is tc_minus and whose integral (times 2^log2_scale, folded into the exponential at no cost) is
+// `value`, still to be passed by the segment's gate.
+PB_DI int pair_721_fast_geometry(const float Rinv[9], float ox2, float oz2, float c4, float oy, float len, float tb0, const Ray& r,
+                                 float extinction, float log2_scale, float& tc_minus_out, float& value) {
   const V3 l = r.l;
-  const float dpx = __builtin_fmaf(f.Rinv[6], l.z, __builtin_fmaf(f.Rinv[3], l.y, f.Rinv[0] * l.x));
-  const float dpz = __builtin_fmaf(f.Rinv[8], l.z, __builtin_fmaf(f.Rinv[5], l.y, f.Rinv[2] * l.x));
+  const float dpx = __builtin_fmaf(Rinv[6], l.z, __builtin_fmaf(Rinv[3], l.y, Rinv[0] * l.x));
+  const float dpz = __builtin_fmaf(Rinv[8], l.z, __builtin_fmaf(Rinv[5], l.y, Rinv[2] * l.x));
   const float a = __builtin_fmaf(dpx, dpx, dpz * dpz);
-  const float b = __builtin_fmaf(f.ox2, dpx, f.oz2 * dpz);
-  const float b24ac = __builtin_fmaf(b, b, -(a * f.c4));
+  const float b = __builtin_fmaf(ox2, dpx, oz2 * dpz);
+  const float b24ac = __builtin_fmaf(b, b, -(a * c4));
   if (b24ac < 0) return 0;
   const float sq = __builtin_amdgcn_sqrtf(b24ac);
   const float inv2a = fast_rcp(a + a);
   const float t0 = (-b - sq) * inv2a;     // a > 0: already ordered, t0 <= t1
   const float t1 = (-b + sq) * inv2a;
   if (!((t0 > 0) && (t1 > t0))) return 1;
-  const float dpy = __builtin_fmaf(f.Rinv[7], l.z, __builtin_fmaf(f.Rinv[4], l.y, f.Rinv[1] * l.x));
-  const float y0 = __builtin_fmaf(t0, dpy, f.oy);
-  const float y1 = __builtin_fmaf(t1, dpy, f.oy);
+  const float dpy = __builtin_fmaf(Rinv[7], l.z, __builtin_fmaf(Rinv[4], l.y, Rinv[1] * l.x));
+  const float y0 = __builtin_fmaf(t0, dpy, oy);
+  const float y1 = __builtin_fmaf(t1, dpy, oy);
   const float y_low = fminf(y0, y1);
   if (fmaxf(y0, y1) < 0.0f || y_low > 1.0f) return 1;               // passes below or above both caps
   const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);         // y of the entry and exit points
@@ -451,21 +462,12 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
   // t0 + (y0 - y) q, with a multiply for which 0 * inf = 0: where no cap is crossed the first factor is 0
   const float thf = t0 + mul_zero_wins(y0 - fy, q);
   const float ths = t1 + mul_zero_wins(y1 - sy, q);
-  const float tc_minus = thf * f.len;
-  const float tc_plus = ths * f.len;
-  const bool sure = (f.qflags & 16u) && (tc_minus < r.maxd * 0.99999f);
-  if (!sure) {
-    // entered behind the surface (or a box that does not hold its cylinder): the box decides.  Its entry
-    // distance first with v_rcp; the exact-order gate only where that lands within 1e-5 of a threshold.
-    const int quick = box_gate_quick(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd);
-    if (quick == 0) return 1;
-    if (quick == 2 && !box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) return 1;
-  } else if (CHECK) {
-    if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) shortcut_wrong++;
-  }
+  const float tc_minus = thf * len;
+  const float tc_plus = ths * len;
+  tc_minus_out = tc_minus;
   const float chord = tc_plus - tc_minus;
   // tc- + tb- = len (th_first + min(fy, sy)) + tb0, and min(fy, sy) is the clamped min(y0, y1)
-  const float reach = __builtin_fmaf(thf + __builtin_amdgcn_fmed3f(y_low, 0.0f, 1.0f), f.len, f.tb0);
+  const float reach = __builtin_fmaf(thf + __builtin_amdgcn_fmed3f(y_low, 0.0f, 1.0f), len, tb0);
   const float cm1 = fabsf(dpy) - 1.0f;
   const float x = extinction * chord * cm1;
   float phi;                                                        // (exp(x) - 1) / x
@@ -473,7 +475,34 @@ PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, 
     phi = __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
   else phi = (__expf(x) - 1.0f) * fast_rcp(x);
   const float fall = __builtin_amdgcn_exp2f(__builtin_fmaf(reach, extinction * -1.44269504f, log2_scale));   // exp(-sigma_t (tc- + tb-))
-  integral_out = (double)(chord * phi * fall);
+  value = chord * phi * fall;
+  return 2;
+}
+
+// The gate of a valid crossing: a segment whose gate box contains its cylinder (qflags bit 4) passes whenever the
+// ray enters the cylinder in front of the surface; otherwise the box decides - its entry distance first with
+// v_rcp, the exact-order gate only where that lands within 1e-5 of a threshold.
+PB_DI bool pair_721_fast_sure(uint32_t qflags, float tc_minus, float maxd) { return (qflags & 16u) && (tc_minus < maxd * 0.99999f); }
+PB_DI bool pair_721_fast_gate(const float lo[3], const float hi[3], const float cand[3], uint32_t qflags, const Ray& r) {
+  const int quick = box_gate_quick(lo, hi, cand, qflags, r.dn, r.maxd);
+  if (quick == 0) return false;
+  if (quick == 2 && !box_gate(lo, hi, cand, qflags, r.dn, r.maxd)) return false;
+  return true;
+}
+
+// log2_scale: the integral is returned times 2^log2_scale (folded into the exponential at no cost).
+template <bool CHECK>
+PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong,
+                             float log2_scale = 0.0f) {
+  float tc_minus, value;
+  const int res = pair_721_fast_geometry(f.Rinv, f.ox2, f.oz2, f.c4, f.oy, f.len, f.tb0, r, extinction, log2_scale, tc_minus, value);
+  if (res != 2) return res;
+  if (!pair_721_fast_sure(f.qflags, tc_minus, r.maxd)) {
+    if (!pair_721_fast_gate(f.lo, f.hi, f.cand, f.qflags, r)) return 1;
+  } else if (CHECK) {
+    if (!box_gate(f.lo, f.hi, f.cand, f.qflags, r.dn, r.maxd)) shortcut_wrong++;
+  }
+  integral_out = (double)value;
   return 2;
 }
 

@@ -9,6 +9,9 @@
 // Built with -ffp-contract=off: the gate (HitBoundingBox + max_distance,
 // BeamRadiance.h:426-430) is discontinuous in its inputs and is evaluated with
 // the reference's exact operation order.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pb_internal.h"
 #include "pb_geom.h"
 #include "pb_grid.h"
@@ -484,8 +487,9 @@ __global__ __launch_bounds__(64) void reduce_kernel(const RenderParams p) {
 // point (PB_FIX_MAGIC), which makes the sum independent of that order and the image reproducible bit
 // for bit.
 // ---------------------------------------------------------------------------
-template <bool COUNT>
-PB_DI void ray_setup_body(const RenderParams& p, int group, int lane) {
+// tris / tri_box: the prepared scene in global memory, or the copy the launch staged in LDS.
+template <bool COUNT, class TriPtr, class BoxPtr>
+PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tris, BoxPtr tri_box) {
   const int nsub = p.ssaa * p.ssaa;
   const int tile = group / nsub, sub = group % nsub;
   const int si = sub / p.ssaa, sj = sub % p.ssaa;
@@ -510,14 +514,14 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane) {
     const float y_lo = (float)((p.y0 + 8 * tk * p.strip_stride) * p.ssaa + sj) - half_h, y_hi = y_lo + (float)(7 * p.ssaa);
     bool may = true;
     if (lane < p.n_tri) {
-      const float4 sb = p.tri_box[lane];
+      const float sb_x = tri_box[lane].x, sb_y = tri_box[lane].y, sb_z = tri_box[lane].z, sb_w = tri_box[lane].w;
       const float m = 1e-4f * p.focal;           // the screen boxes are in units of x / z, the rays' z is focal
-      may = !(x_hi < sb.x * p.focal - m * (1.0f + fabsf(sb.x)) || x_lo > sb.y * p.focal + m * (1.0f + fabsf(sb.y)) ||
-              y_hi < sb.z * p.focal - m * (1.0f + fabsf(sb.z)) || y_lo > sb.w * p.focal + m * (1.0f + fabsf(sb.w)));
+      may = !(x_hi < sb_x * p.focal - m * (1.0f + fabsf(sb_x)) || x_lo > sb_y * p.focal + m * (1.0f + fabsf(sb_y)) ||
+              y_hi < sb_z * p.focal - m * (1.0f + fabsf(sb_z)) || y_lo > sb_w * p.focal + m * (1.0f + fabsf(sb_w)));
     }
     tri_mask = __ballot(may);
   }
-  Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj, tri_mask);
+  Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj, tri_mask, tris, tri_box);
   r.active = r.active && in_image;
   const bool hit_scene = r.active;
   r.active = r.active && box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd);
@@ -525,7 +529,16 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane) {
   float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
   rr[0 * 64 + lane] = r.l.x; rr[1 * 64 + lane] = r.l.y; rr[2 * 64 + lane] = r.l.z;
   rr[3 * 64 + lane] = r.dn.x; rr[4 * 64 + lane] = r.dn.y; rr[5 * 64 + lane] = r.dn.z;
-  rr[6 * 64 + lane] = r.maxd; rr[7 * 64 + lane] = 0.0f;
+  // row 7, lanes 0..11: the four side planes of the tile's pyramid, which every evaluation item of the tile needs
+  float plane_word = 0.0f;
+  {
+    V3 pl[4];
+    tile_planes(p, tx, tk, pl);
+    const float w[12] = {pl[0].x, pl[0].y, pl[0].z, pl[1].x, pl[1].y, pl[1].z, pl[2].x, pl[2].y, pl[2].z, pl[3].x, pl[3].y, pl[3].z};
+#pragma unroll
+    for (int j = 0; j < 12; ++j) plane_word = (lane == j) ? w[j] : plane_word;
+  }
+  rr[6 * 64 + lane] = r.maxd; rr[7 * 64 + lane] = plane_word;
   rr[8 * 64 + lane] = r.d1.x; rr[9 * 64 + lane] = r.d1.y; rr[10 * 64 + lane] = r.d1.z; rr[11 * 64 + lane] = 0.0f;
   const bool any = __ballot(r.active) != 0ull;
   if (lane == 0) p.group_last[group] = any ? 0 : -1;
@@ -548,7 +561,7 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane) {
 
 template <bool COUNT>
 __global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
-  ray_setup_body<COUNT>(p, blockIdx.x, threadIdx.x);
+  ray_setup_body<COUNT>(p, blockIdx.x, threadIdx.x, p.tris, p.tri_box);
 }
 
 // Inward unit normals of the side planes of the pyramid spanned by the sub-rays of the pixel rectangle
@@ -756,18 +769,18 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const RenderParams p, 
 // the pyramid of its own macro tile, whose planes it sets up once: no walk over a segment's tiles, no
 // dependent memory access per segment, and a segment's incidences with all macro tiles cost one pass of about
 // sixty instructions.  What a lane found is a bit mask over the wave's segments, so positions inside a list follow
-// from bit counts: per (wave, macro tile) counts go to LDS, one thread per macro tile turns them into the waves'
-// offsets and reserves the block's range with ONE global atomic (same-address device atomics run at about 12 ns
-// each), and the fill pass then writes every lane's segments in ascending order.  COUNT pass: only the totals.
-// The fill pass of a frame whose list offsets are already known (sub_off kept from the frame that sized the
-// workspace for this segment set and frame geometry) needs no count pass before it.
-constexpr int MBIN_THREADS = 1024;
-constexpr int MBIN_WAVES = MBIN_THREADS / 64;
+// from bit counts: per (wave, macro tile) counts go to LDS and one thread per macro tile turns them into the waves'
+// offsets inside the block's range.  The count pass stores the block's total per macro tile in blk[block][macro];
+// queue_build_kernel turns those into the start of the block's range inside the macro tile's list; the fill pass
+// reads that start and writes every lane's segments in ascending order.  No atomics, no counters to clear, and a
+// list holds its segments in ascending order whatever the order the blocks ran in.  The fill pass of a frame whose
+// offsets are already in place (blk and sub_off kept from the frame that sized the workspace for this segment set
+// and frame geometry) needs no count pass before it.
+constexpr int MBIN_WAVES = PB_MBIN_WAVES;
+constexpr int MBIN_THREADS = 64 * MBIN_WAVES;
 constexpr int MBIN_CHUNKS = 4;            // 64 macro tiles per chunk: QUEUE_FUSED_MACROS = 256
 PB_DI float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
-PB_HDI int pb_mbin_spw(int n_seg) { return n_seg <= 4096 ? 4 : (n_seg <= 32768 ? 16 : 32); }
-PB_HDI int pb_mbin_blocks(int n_seg) { const int per = MBIN_WAVES * pb_mbin_spw(n_seg); return (n_seg + per - 1) / per; }
 PB_HDI size_t pb_mbin_lds_bytes(int n_macro) { return sizeof(uint32_t) * (size_t)(MBIN_WAVES + 1) * (size_t)n_macro; }
 
 template <bool FILL>
@@ -813,10 +826,8 @@ PB_DI void macro_bin_body(const RenderParams& p, int n_macro, uint32_t* lds, int
   for (int m = tid; m < n_macro; m += MBIN_THREADS) {
     uint32_t run = 0;
     for (int w = 0; w < MBIN_WAVES; ++w) { const uint32_t c = lwave[w * n_macro + m]; lwave[w * n_macro + m] = run; run += c; }
-    if (run) {
-      if (FILL) lbase[m] = p.sub_off[m] + atomicAdd(&p.sub_fill[m], run);
-      else atomicAdd(&p.sub_count[m], run);
-    }
+    if (FILL) lbase[m] = p.sub_off[m] + p.blk[(size_t)block * n_macro + m];
+    else p.blk[(size_t)block * n_macro + m] = run;
   }
   if (!FILL) return;
   __syncthreads();
@@ -918,20 +929,40 @@ __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, i
 // a launch with a step that does not depend on them.  Blocks [0, bin_blocks) bin; the others set up rays,
 // one ray group per wave (count pass), or write the evaluation items (fill pass).
 constexpr int ITEM_LANES = 64;
-__global__ __launch_bounds__(BIN_THREADS) void setup_count_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups) {
-  extern __shared__ uint32_t bin_lds[];
+// Ray set-up of a 1024-thread block: sixteen ray groups, one per wave.  The prepared triangles and their screen
+// boxes (80 bytes per triangle, adjacent in memory) are first copied to LDS by the whole block in one round trip:
+// read one triangle at a time through the scalar unit, a wave paid a dependent trip to L2 for every triangle its
+// tile can see.
+constexpr int SCENE_LDS_MAX_TRI = 256;
+PB_DI void ray_role(const RenderParams& p, uint32_t* lds, int ray_block, int groups, int scene_in_lds) {
+  struct Box4 { float x, y, z, w; };
+  typedef __attribute__((address_space(3))) float LdsFloat;
+  typedef __attribute__((address_space(3))) Box4 LdsBox4;
+  typedef __attribute__((address_space(3))) TriPrep LdsTriPrep;
+  const int group = ray_block * (BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
+  if (scene_in_lds) {
+    LdsFloat* dst = (LdsFloat*)lds;
+    const float* src = (const float*)p.tris;            // n_tri TriPrep records (16 floats), then n_tri screen boxes (4)
+    for (int i = threadIdx.x; i < p.n_tri * 20; i += BIN_THREADS) dst[i] = src[i];
+    __syncthreads();
+    if (group < groups)
+      ray_setup_body<false>(p, group, threadIdx.x & 63, (const LdsTriPrep*)lds, (const LdsBox4*)lds + 4 * p.n_tri);
+  } else if (group < groups) {
+    ray_setup_body<false>(p, group, threadIdx.x & 63, p.tris, p.tri_box);
+  }
+}
+__global__ __launch_bounds__(BIN_THREADS) void setup_count_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups, int scene_in_lds) {
+  extern __shared__ __align__(16) uint32_t bin_lds[];
   if ((int)blockIdx.x < bin_blocks) { macro_bin_body<false>(p, n_macro, bin_lds, blockIdx.x); return; }
-  const int group = ((int)blockIdx.x - bin_blocks) * (BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
-  if (group < groups) ray_setup_body<false>(p, group, threadIdx.x & 63);
+  ray_role(p, bin_lds, (int)blockIdx.x - bin_blocks, groups, scene_in_lds);
 }
 
 // A frame whose list offsets and evaluation items are in place (kept from the frame that sized the workspace for this
 // segment set and frame geometry): ray set-up beside the one binning pass it needs, the fill.
-__global__ __launch_bounds__(BIN_THREADS) void setup_fill_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups) {
-  extern __shared__ uint32_t bin_lds[];
+__global__ __launch_bounds__(BIN_THREADS) void setup_fill_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups, int scene_in_lds) {
+  extern __shared__ __align__(16) uint32_t bin_lds[];
   if ((int)blockIdx.x < bin_blocks) { macro_bin_body<true>(p, n_macro, bin_lds, blockIdx.x); return; }
-  const int group = ((int)blockIdx.x - bin_blocks) * (BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
-  if (group < groups) ray_setup_body<false>(p, group, threadIdx.x & 63);
+  ray_role(p, bin_lds, (int)blockIdx.x - bin_blocks, groups, scene_in_lds);
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void fill_items_kernel(const RenderParams p, int n_macro, int bin_blocks, int n_tiles) {
@@ -946,12 +977,22 @@ __global__ __launch_bounds__(BIN_THREADS) void fill_items_kernel(const RenderPar
 // list offsets of the macro tiles, their rank by list length, items per queue slot and their prefix sum.  Small frames spend more time between launches than in these steps.
 constexpr int QUEUE_FUSED_MACROS = 256;            // macro tiles the single-block queue build holds in LDS
 constexpr int QUEUE_THREADS = 1024;
-__global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const RenderParams p, int n_macro) {
+__global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const RenderParams p, int n_macro, int bin_blocks) {
   __shared__ uint32_t s_cnt[256], s_inv[256], s_part[QUEUE_THREADS / 64];
   const int t = threadIdx.x;
   const int nsub = p.ssaa * p.ssaa;
   const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
-  if (t < n_macro) s_cnt[t] = p.sub_count[t];
+  if (t < n_macro) {
+    // list length of macro tile t = sum of the binning blocks' counts, each replaced by the sum of those before it
+    uint32_t run = 0;
+    for (int b = 0; b < bin_blocks; ++b) {
+      uint32_t* at = p.blk + (size_t)b * n_macro + t;
+      const uint32_t c = *at;
+      *at = run;
+      run += c;
+    }
+    s_cnt[t] = run;
+  }
   __syncthreads();
   if (t < n_macro) {
     const uint32_t mine = s_cnt[t];
@@ -1142,6 +1183,127 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   eval_bins_body<false, false, PB_MODE_721>(p, surv);
 }
 
+// The default estimator again, one wave per item, with the record loads of the pair loop taken off its critical path.
+// eval_bins_fast_kernel fetches a candidate's record and waits for it before the first instruction that uses it: a
+// round trip to L2 per candidate, hidden only by other waves (rocprofv3: 36 % of the wave cycles parked on that wait).
+// Here the loop keeps two loads in flight while it computes: the half of the current record that only the end of the
+// iteration reads (radiance weights, gate box) and the first half of the next candidate's record (everything
+// HitCylinder and Integral_721 need).  Scalar loads return out of order, so the one wait per iteration is for both;
+// it sits behind the geometry of the current pair.  The loads and the wait are written as inline assembly: the
+// compiler would otherwise sink a load to its first use, and it does not see inline-assembly loads when it places
+// its own waits, which only makes those waits stricter.  The survivors' indices sit in a VGPR (lane j: survivor j)
+// and are picked with v_readlane, so the loop touches LDS once per 64 candidates.  The tile's pyramid planes come
+// from row 7 of its ray block (ray_setup_body) instead of being normalised again by every item.
+struct SegHalfA { float Rinv[9]; float ox2, oz2, c4, oy, len, tb0; uint32_t qflags; };      // SegFrame dwords 0..15
+struct SegHalfB { double W[3]; float lo[3], hi[3], cand[3]; float Sinv; };                  // SegFrame dwords 16..31
+static_assert(sizeof(SegHalfA) == 64 && sizeof(SegHalfB) == 64, "halves of the first 128 bytes of SegFrame");
+
+PB_DI void smem_load16(u32x16& dst, const SegFrame* base, uint32_t byte_offset) {
+  asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(dst) : "s"(base), "s"(byte_offset));
+}
+PB_DI void smem_wait(u32x16& a, u32x16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+PB_DI void smem_wait(u32x16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+
+struct PairSums { unsigned long long ai[3]; unsigned long long ag; uint32_t nc; };
+
+// One candidate: `cur` holds the first half of its record (loaded and waited for); requests the second half and the
+// first half of the next candidate's record into `nxt`, evaluates, waits, accumulates.
+PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t off_cur, uint32_t off_nxt, const Ray& r,
+                     float extinction, PairSums& sum) {
+  u32x16 second;
+  smem_load16(second, frames, off_cur + 64u);
+  smem_load16(nxt, frames, off_nxt);
+  SegHalfA a;
+  __builtin_memcpy(&a, &cur, 64);
+  float tc_minus = 0.0f, value = 0.0f;
+  const int res = pair_721_fast_geometry(a.Rinv, a.ox2, a.oz2, a.c4, a.oy, a.len, a.tb0, r, extinction, -10.0f, tc_minus, value);
+  smem_wait(second, nxt);
+  SegHalfB b;
+  __builtin_memcpy(&b, &second, 64);
+  bool ok = res == 2;
+  if (ok && !pair_721_fast_sure(a.qflags, tc_minus, r.maxd)) ok = pair_721_fast_gate(b.lo, b.hi, b.cand, a.qflags, r);
+  if (ok) {
+    const double integral = (double)value;               // carries the 2^-10 of the fixed-point sums
+    if (a.qflags & 64u) {
+      sum.ag += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
+    } else {
+      sum.ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
+      sum.ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[1], integral, PB_FIX_MAGIC));
+      sum.ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[2], integral, PB_FIX_MAGIC));
+    }
+    sum.nc++;
+  }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_items_fast_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  const int lane = threadIdx.x;
+  const uint32_t produced = p.ctrl[0];
+  const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
+  const uint32_t c = blockIdx.x;
+  if (c >= n_items) return;
+  const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
+  const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
+  const int group = (int)it[0];
+  const uint32_t start = it[1];
+  const int cn = (int)it[2];
+  const int tile = group / (p.ssaa * p.ssaa);
+  const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+  V3 pl[4];
+  {
+    const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
+    pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
+  }
+  Ray r;
+  r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+  r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
+  r.maxd = rr[6 * 64 + lane];
+  r.d1 = r.dn;
+  r.active = r.maxd >= 0.0f;
+  // 1. lanes test the candidates against this tile's pyramid, 64 at a time; survivors are compacted into LDS
+  int ns = 0;
+  for (int base = 0; base < cn; base += 64) {
+    const int k = base + lane;
+    const uint32_t cand = (k < cn) ? p.bin_list[start + k] : 0xffffffffu;
+    bool touch = false;
+    if (cand != 0xffffffffu) touch = axis_touches_pyramid(p.capA[cand], p.capB[cand], pl);
+    const unsigned long long mask = __ballot(touch);
+    if (touch) surv[ns + (int)lanes_below(mask)] = cand;
+    ns += __builtin_popcountll(mask);
+  }
+  __syncthreads();
+  // 2. every lane evaluates its own ray against each survivor
+  PairSums sum;
+  sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = 0u;
+  const SegFrame* frames = p.frames;
+  const float extinction = p.extinction_c;
+  for (int b0 = 0; b0 < ns; b0 += 64) {
+    const int nb = (ns - b0) < 64 ? (ns - b0) : 64;
+    const int mine = (lane < nb) ? (int)surv[b0 + lane] : 0;
+    uint32_t off_cur = (uint32_t)__builtin_amdgcn_readlane(mine, 0) * (uint32_t)sizeof(SegFrame);
+    u32x16 ra, rb;
+    smem_load16(ra, frames, off_cur);
+    smem_wait(ra);
+    int k = 0;
+    for (; k + 1 < nb; k += 2) {
+      const uint32_t off1 = (uint32_t)__builtin_amdgcn_readlane(mine, k + 1) * (uint32_t)sizeof(SegFrame);
+      const int k2 = (k + 2 < nb) ? k + 2 : nb - 1;
+      const uint32_t off2 = (uint32_t)__builtin_amdgcn_readlane(mine, k2) * (uint32_t)sizeof(SegFrame);
+      pair_step(frames, ra, rb, off_cur, off1, r, extinction, sum);
+      pair_step(frames, rb, ra, off1, off2, r, extinction, sum);
+      off_cur = off2;
+    }
+    if (k < nb) pair_step(frames, ra, rb, off_cur, off_cur, r, extinction, sum);
+  }
+  if (sum.nc) {
+    unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
+    const unsigned long long bias = (unsigned long long)sum.nc * magic_bits;
+    atomicAdd(&dst[0], sum.ai[0] + sum.ag - bias);
+    atomicAdd(&dst[64], sum.ai[1] + sum.ag - bias);
+    atomicAdd(&dst[128], sum.ai[2] + sum.ag - bias);
+  }
+}
+
 // Frames of the estimators whose integral is long: Integral_73Het / Integral_73 (closest approach in double, a
 // walk through the grid along the view ray) and BeamRadiance's dispatch (Integral_721_ada's Riemann sum).  About
 // one candidate-lane pair in four is a valid hit, so evaluating the integral inside the pair loop leaves most
@@ -1289,11 +1451,6 @@ __global__ __launch_bounds__(256) void beam_axis_kernel(const float4* __restrict
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
-  if (p.fused_queue && blockIdx.x == 0) {
-    // the bin counters of the next frame start at zero (the queue and the lists have been consumed)
-    const int n_macro = pb_macro_count(p);
-    for (int m = threadIdx.x; m < n_macro; m += blockDim.x) { p.sub_count[m] = 0u; p.sub_fill[m] = 0u; }
-  }
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)p.out_w * p.out_h;
   if (i >= n) return;
@@ -1357,8 +1514,10 @@ int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
     const int n_macro = pb_macro_count(p);
     const int bin_blocks = pb_mbin_blocks(p.n_seg);
     const int ray_blocks = (groups + BIN_THREADS / 64 - 1) / (BIN_THREADS / 64);
-    hipLaunchKernelGGL(setup_count_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), pb_mbin_lds_bytes(n_macro), s,
-                       p, n_macro, bin_blocks, groups);
+    const int scene_in_lds = p.n_tri <= SCENE_LDS_MAX_TRI ? 1 : 0;
+    const size_t lds = std::max(pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)80 * p.n_tri : (size_t)0);
+    hipLaunchKernelGGL(setup_count_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), lds, s,
+                       p, n_macro, bin_blocks, groups, scene_in_lds);
     PB_HIP(hipGetLastError());
     return PB_OK;
   }
@@ -1390,7 +1549,7 @@ int pb_launch_bin_count(const RenderParams& p, bool count, hipStream_t s) {
   const int n_macro = pb_macro_count(p);
   if (p.n_seg > 0 && !shares_launches(p, count)) launch_bin_pass<false>(p, n_macro, s);
   if (p.fused_queue) {
-    hipLaunchKernelGGL(queue_build_kernel, dim3(1), dim3(QUEUE_THREADS), 0, s, p, n_macro);
+    hipLaunchKernelGGL(queue_build_kernel, dim3(1), dim3(QUEUE_THREADS), 0, s, p, n_macro, p.n_seg > 0 ? pb_mbin_blocks(p.n_seg) : 0);
   } else {
     hipLaunchKernelGGL(macro_count_kernel, dim3((n_macro + 255) / 256), dim3(256), 0, s, p, n_macro);
     hipLaunchKernelGGL(macro_rank_kernel, dim3((n_macro + 255) / 256), dim3(256), 0, s, p, n_macro);
@@ -1417,6 +1576,8 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
   else if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (p.precise) hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
+  else if (p.eval_waves <= 0 && (size_t)p.n_seg * sizeof(SegFrame) < ((size_t)1 << 31) && !std::getenv("PB_OLD_EVAL"))
+    hipLaunchKernelGGL(eval_items_fast_kernel, dim3(waves), dim3(64), 0, s, p);
   else hipLaunchKernelGGL(eval_bins_fast_kernel, dim3(waves), dim3(64), 0, s, p);
   const size_t px = (size_t)p.out_w * p.out_h;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, p);
@@ -1448,8 +1609,10 @@ int pb_launch_fast_frame(const RenderParams& p, int mode, hipStream_t s) {
   const int n_macro = pb_macro_count(p);
   const int bin_blocks = pb_mbin_blocks(p.n_seg);
   const int ray_blocks = (groups + BIN_THREADS / 64 - 1) / (BIN_THREADS / 64);
-  hipLaunchKernelGGL(setup_fill_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), pb_mbin_lds_bytes(n_macro), s,
-                     p, n_macro, bin_blocks, groups);
+  const int scene_in_lds = p.n_tri <= SCENE_LDS_MAX_TRI ? 1 : 0;
+  const size_t lds = std::max(pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)80 * p.n_tri : (size_t)0);
+  hipLaunchKernelGGL(setup_fill_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), lds, s,
+                     p, n_macro, bin_blocks, groups, scene_in_lds);
   return launch_eval_finalize(p, mode, false, s);
 }
 

@@ -56,7 +56,7 @@ def is_frame_kernel(name):
 def run_pass(workload, out_dir, name, extra):
     d = os.path.join(out_dir, f"{workload}_{name}")
     cmd = ["rocprofv3"] + extra + ["-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload,
-                                   "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--in-flight", "0"]
+                                   "--only", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--in-flight", "0"]
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
     open(os.path.join(out_dir, f"{workload}_{name}.log"), "w").write(r.stdout)
@@ -115,7 +115,7 @@ def main():
     fetch = sum(2 * 1024.0 * v.get("FETCH_SIZE", 0) for v in frame.values())
     write = sum(1024.0 * v.get("WRITE_SIZE", 0) for v in frame.values())
     out = {"workload": workload, "cull": "bins", "source_stamp": source_stamp(),
-           "method": "rocprofv3 --pmc, one pass per counter group, over `python3 bench.py --workload W --steps 20 --warmup 3 "
+           "method": "rocprofv3 --pmc, one pass per counter group, over `python3 bench.py --workload W --only --steps 20 --warmup 3 "
                      "--no-cpu-baseline --in-flight 0`; per kernel the mean per launch; frame sums leave out the one-time "
                      "passes and the counted frame; fp32_flop = 64 x (ADD_F32 + MUL_F32 + 2 FMA_F32 + TRANS_F32) wave-level "
                      "instructions; FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)",
