@@ -113,7 +113,9 @@ typedef struct pb_stats {
                                 (BeamRadiance.h:428-439); counted by a full scan   */
   uint64_t shortcut_wrong;   /* pairs that the fast gate shortcut accepted and the exact
                                 HitBoundingBox gate would have rejected (expected: 0)  */
-  float ms_render;           /* device time of the last pb_render (HIP events)    */
+  float ms_render;           /* device time of the last pb_render, or of the last pb_render_*_d with counters on
+                                (HIP events; the device-pointer calls record none otherwise: two event packets cost
+                                a small frame a tenth of its time)                */
   float ms_build;            /* device time of the last pb_build_lbvh             */
   float ms_prepare;          /* device time of the last segment upload/prepare    */
   float ms_emit;             /* device time of the last pb_emit_beams             */

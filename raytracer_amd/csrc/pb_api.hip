@@ -249,11 +249,13 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     if (rc != PB_OK) return rc;
     // With interleaved strips a macro tile takes fewer tile rows: eight would span strip_stride times the
     // height on screen and hand every tile the segments of a whole column to refine.
-    p.macro_h = PB_MACRO / p.strip_stride;     // keeps a macro tile's footprint at 64 image rows
+    p.macro_w = PB_MACRO;
+    if (const char* e = std::getenv("PB_TUNE_MACROW")) { int v = std::atoi(e); if (v >= 1 && v <= PB_MACRO) p.macro_w = v; }
+    p.macro_h = p.macro_w / p.strip_stride;     // keeps a macro tile's footprint square on screen
     if (p.macro_h < 1) p.macro_h = 1;
     if (const char* e = std::getenv("PB_TUNE_MACROH")) { int v = std::atoi(e); if (v >= 1 && v <= PB_MACRO) p.macro_h = v; }
     const int mtiles = pb_macro_count(p);
-    const int slots = mtiles * PB_MACRO * p.macro_h;     // queue slots: every macro tile has room for all its tiles
+    const int slots = mtiles * p.macro_w * p.macro_h;     // queue slots: every macro tile has room for all its tiles
     rc = ensure_bin_workspace(ws, slots, want_bins, want_items, px);
     if (rc != PB_OK) return rc;
     p.rays = ws.d_rays; p.group_last = ws.d_group_last; p.ctrl = ws.d_ctrl;
@@ -264,8 +266,11 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       p.sub_count = ws.d_tile_u32 + 4 * T; p.sub_fill = p.sub_count + T * PB_BIN_SUBS; p.sub_off = p.sub_fill + T * PB_BIN_SUBS;
     }
     p.bin_list = ws.d_bin_list; p.items = ws.d_items; p.accum = ws.d_accum;
+    p.tile_items = p.tile_done = nullptr; p.finalize_in_eval = 0;
     p.bin_capacity = ws.ws_bin_cap; p.item_capacity = ws.ws_item_cap;
     p.fused_queue = (mtiles <= pb_fused_queue_macros()) ? 1 : 0;
+    // frames whose queue one block builds bin without atomics: the counters' space holds the per-tile item counts
+    if (p.fused_queue) { p.tile_items = p.sub_count; p.tile_done = p.sub_fill; }
     p.bin_mask = nullptr;
     p.blk = nullptr;
     if (p.fused_queue && p.n_seg > 0) {
@@ -273,15 +278,15 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       if (rc != PB_OK) return rc;
       p.blk = ws.d_blk;
     }
-    PB_HIP(hipEventRecord(ctx->ev[0], s));
+    if (ctx->count_on || ctx->time_render) PB_HIP(hipEventRecord(ctx->ev[0], s));
     if (verified && ws.queue_kept && p.fused_queue && !ctx->count_on && p.n_seg > 0) {
       // The list offsets and the item queue are functions of the segment set and the frame geometry alone and are in
       // the workspace from the frame that sized it for this key: ray set-up + the fill of the lists, evaluation, pixels.
       p.n_items_host = ws.ws_items_needed;
+      p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !std::getenv("PB_SEPARATE_FINALIZE")) ? 1 : 0;
       rc = pb_launch_fast_frame(p, mode, s);
       if (rc != PB_OK) return rc;
-      PB_HIP(hipEventRecord(ctx->ev[1], s));
-      ctx->ev_valid[0] = true;
+      if (ctx->count_on || ctx->time_render) { PB_HIP(hipEventRecord(ctx->ev[1], s)); ctx->ev_valid[0] = true; }
       return PB_OK;
     }
     if (!p.fused_queue) {
@@ -342,8 +347,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
   int rc = pb_launch_bin_fill_eval(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
   ws.queue_kept = p.fused_queue != 0 && p.n_seg > 0;
-  PB_HIP(hipEventRecord(ctx->ev[1], s));
-  ctx->ev_valid[0] = true;
+  if (ctx->count_on || ctx->time_render) { PB_HIP(hipEventRecord(ctx->ev[1], s)); ctx->ev_valid[0] = true; }
   return PB_OK;
 }
 
@@ -419,7 +423,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
     p.rays = ws.d_rays; p.group_last = ws.d_group_last; p.chunks = ws.d_chunks;
     p.partials = ws.d_partials; p.ctrl = ws.d_ctrl; p.chunk_capacity = ws.ws_chunks;
     PB_HIP(hipMemsetAsync(ws.d_ctrl, 0, sizeof(uint32_t) * 4, s));
-    PB_HIP(hipEventRecord(ctx->ev[0], s));
+    if (ctx->count_on || ctx->time_render) PB_HIP(hipEventRecord(ctx->ev[0], s));
     rc = pb_launch_cull(p, mode, ctx->count_on, s);
     if (rc != PB_OK) return rc;
     if (verified) break;
@@ -440,8 +444,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   p.n_items_host = ws.ws_items_needed;
   int rc = pb_launch_eval_reduce(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
-  PB_HIP(hipEventRecord(ctx->ev[1], s));
-  ctx->ev_valid[0] = true;
+  if (ctx->count_on || ctx->time_render) { PB_HIP(hipEventRecord(ctx->ev[1], s)); ctx->ev_valid[0] = true; }
   return PB_OK;
 }
 
@@ -759,7 +762,9 @@ int pb_render(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbvh,
     PB_HIP(hipMalloc(&ctx->d_out, sizeof(float) * need));
     ctx->out_floats = need;
   }
+  ctx->time_render = true;       // this call waits for the frame anyway: its device time is recorded (pb_stats.ms_render)
   rc = pb_render_d(ctx, x0, y0, w, h, mode, use_lbvh, ctx->d_out, ctx->stream);
+  ctx->time_render = false;
   if (rc != PB_OK) return rc;
   PB_HIP(hipMemcpyAsync(rgb_out, ctx->d_out, sizeof(float) * need, hipMemcpyDeviceToHost, ctx->stream));
   PB_HIP(hipStreamSynchronize(ctx->stream));

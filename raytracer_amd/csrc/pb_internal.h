@@ -146,9 +146,13 @@ struct RenderParams {
   uint32_t* item_off;       // [queue slots] first item of the tile in that slot (macro tiles in rank order)
   uint32_t* macro_cnt;      // [macro tiles] list length
   uint32_t* macro_rank;     // [macro tiles] position in the evaluation queue, longest list first
+  uint32_t* tile_items;     // [tiles] evaluation items of the tile (written with the items, kept with them)
+  uint32_t* tile_done;      // [tiles] items of the tile that have added their sums this frame (finalize_in_eval)
+  int finalize_in_eval;     // 1: the last item of a tile writes its pixels; tiles without items are written by ray set-up
   unsigned long long* accum;// [out_h*out_w][3] fixed-point radiance sums
   int bin_capacity, item_capacity;
-  int macro_h;              // tile rows per macro tile: PB_MACRO, or 1 when the rows are interleaved strips
+  int macro_w;              // tile columns per macro tile
+  int macro_h;              // tile rows per macro tile (fewer when the rows are interleaved strips)
   int fused_queue;          // 1: ray set-up clears the accumulators and one block builds the queue (small frames)
   int n_items_host;         // number of items of this frame as measured when the workspace was sized
   int slice;                // candidates of a macro list per evaluation item (<= PB_SLICE)
@@ -165,7 +169,7 @@ constexpr int PB_RAY_WORDS = 12;       // floats stored per camera ray
 constexpr int PB_CHUNK = 124;          // candidates per chunk
 constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 512 B
 constexpr int PB_EVAL_WAVES = 256 * 32;
-constexpr int PB_MACRO = 8;             // a macro tile is PB_MACRO tiles wide and RenderParams::macro_h tiles tall
+constexpr int PB_MACRO = 8;             // most tiles a macro tile is wide or tall (RenderParams::macro_w x macro_h)
 constexpr int PB_SLICE = 512;           // candidates of a macro list handed to one evaluation item
 constexpr int PB_BIN_FAN = 8;            // lanes that share the macro rows of one segment in the binning passes
 constexpr int PB_BIN_SUBS = 1;          // sub-counters per tile in the binning passes (power of two)
@@ -271,6 +275,7 @@ struct pb_ctx {
   // counters
   unsigned long long* d_counters = nullptr;
   bool count_on = false;
+  bool time_render = false;               // record the frame's HIP events although counters are off (host-pointer pb_render)
   bool precise = false;
   int tune_slice = 0, tune_waves = 0;     // 0: defaults chosen per frame   // PB_TUNE_SLICE / PB_TUNE_WAVES environment overrides
   pb_stats stats;
@@ -303,12 +308,13 @@ int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream
 int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);
 int pb_launch_bin_count(const RenderParams& p, bool count, hipStream_t s);
 int pb_fused_queue_macros(void);
+bool pb_pipelined_eval(const RenderParams& p, int mode);
 // Lane-per-macro-tile binning (pb_render.hip): segments per wave and blocks of 16 waves for a segment count.
 constexpr int PB_MBIN_WAVES = 16;
 PB_HDI int pb_mbin_spw(int n_seg) { return n_seg <= 4096 ? 4 : (n_seg <= 32768 ? 16 : 32); }
 PB_HDI int pb_mbin_blocks(int n_seg) { const int per = PB_MBIN_WAVES * pb_mbin_spw(n_seg); return (n_seg + per - 1) / per; }
 PB_HDI int pb_macro_count(const RenderParams& p) {
-  return ((p.tiles_x + PB_MACRO - 1) / PB_MACRO) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
+  return ((p.tiles_x + p.macro_w - 1) / p.macro_w) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
 }
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_fast_frame(const RenderParams& p, int mode, hipStream_t s);

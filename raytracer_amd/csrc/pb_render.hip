@@ -503,6 +503,14 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
     if (sub == 0) {
       unsigned long long* a = p.accum + (size_t)tile * 3 * 64 + lane;   // [tile][channel][lane]
       a[0] = 0ull; a[64] = 0ull; a[128] = 0ull;
+      if (p.finalize_in_eval) {
+        if (lane == 0) p.tile_done[tile] = 0u;
+        // no evaluation item will come by this tile: its pixels are written here
+        if (pb_uniform(p.tile_items)[tile] == 0u && ox < p.out_w && oy < p.out_h) {
+          float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
+          o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+        }
+      }
     }
   }
   // Triangles whose screen box misses the whole tile are ruled out once per wave (lane i looks at triangle i)
@@ -600,7 +608,7 @@ PB_DI TileRect macro_rect(const RenderParams& p, V3 a, V3 b, float pad, int mtx,
   }
   // sub-ray coordinate s = u * focal + half; pixel = s / ssaa; one pixel of margin
   const float inv = 1.0f / (float)p.ssaa;
-  const float sx = 1.0f / (float)(8 * PB_MACRO), sy = 1.0f / (float)(8 * p.macro_h * p.strip_stride);
+  const float sx = 1.0f / (float)(8 * p.macro_w), sy = 1.0f / (float)(8 * p.macro_h * p.strip_stride);
   const float fx0 = ((lo[0] * p.focal + half_w) * inv - 1.0f - (float)p.x0) * sx;
   const float fx1 = ((hi[0] * p.focal + half_w) * inv + 1.0f - (float)p.x0) * sx;
   const float fy0 = ((lo[1] * p.focal + half_h) * inv - 1.0f - (float)p.y0) * sy;
@@ -644,8 +652,8 @@ PB_DI void for_each_macro_tile(const RenderParams& p, const float4 A4, const flo
     if (!clip_axis(normalize3(v3(0.0f, p.focal, -yt)), A4, B4, pad, r0, r1)) continue;
     if (!clip_axis(normalize3(v3(0.0f, -p.focal, yb)), A4, B4, pad, r0, r1)) continue;
     for (int mx = rc.x0; mx <= rc.x1; ++mx) {
-      const int tx0 = mx * PB_MACRO;
-      int tx1 = tx0 + PB_MACRO - 1;
+      const int tx0 = mx * p.macro_w;
+      int tx1 = tx0 + p.macro_w - 1;
       if (tx1 > p.tiles_x - 1) tx1 = p.tiles_x - 1;
       const int px0 = p.x0 + 8 * tx0, px1 = p.x0 + 8 * tx1 + 7;
       const float xl = (float)(px0 * p.ssaa) - half_w - 0.5f;
@@ -707,7 +715,7 @@ template <bool FILL, bool LDS>
 PB_DI void bin_body(const RenderParams& p, int n_macro, uint32_t* bin_lds, int block) {
   uint32_t* lcount = bin_lds;               // [n_macro] counts, [n_macro] bases
   uint32_t* lbase = bin_lds + n_macro;
-  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO, mty = (p.tiles_y + p.macro_h - 1) / p.macro_h;
+  const int mtx = (p.tiles_x + p.macro_w - 1) / p.macro_w, mty = (p.tiles_y + p.macro_h - 1) / p.macro_h;
   const long long g = (long long)block * BIN_THREADS + threadIdx.x;
   const int s = (int)(g / PB_BIN_FAN), k = (int)(g % PB_BIN_FAN);
   const bool live = s < p.n_seg;
@@ -789,7 +797,7 @@ PB_DI void macro_bin_body(const RenderParams& p, int n_macro, uint32_t* lds, int
   uint32_t* lwave = lds;                               // [MBIN_WAVES][n_macro] counts, then offsets inside the block's range
   uint32_t* lbase = lds + MBIN_WAVES * n_macro;        // [n_macro] start of the block's range in bin_list
   const int spw = pb_mbin_spw(p.n_seg);
-  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
+  const int mtx = (p.tiles_x + p.macro_w - 1) / p.macro_w;
   const int seg0 = (block * MBIN_WAVES + wave) * spw;
   int n_here = p.n_seg - seg0;
   n_here = n_here < 0 ? 0 : (n_here > spw ? spw : n_here);
@@ -805,8 +813,8 @@ PB_DI void macro_bin_body(const RenderParams& p, int n_macro, uint32_t* lds, int
       const int my = m / mtx, mx = m % mtx;
       // pixel rectangle of macro tile (mx, my); with interleaved strips its tile rows are strip_stride apart and the
       // pyramid also spans the rows in between: conservative
-      const int tx0 = mx * PB_MACRO, tk0 = my * p.macro_h;
-      int tx1 = tx0 + PB_MACRO - 1, tk1 = tk0 + p.macro_h - 1;
+      const int tx0 = mx * p.macro_w, tk0 = my * p.macro_h;
+      int tx1 = tx0 + p.macro_w - 1, tk1 = tk0 + p.macro_h - 1;
       if (tx1 > p.tiles_x - 1) tx1 = p.tiles_x - 1;
       if (tk1 > p.tiles_y - 1) tk1 = p.tiles_y - 1;
       V3 pl[4];
@@ -879,10 +887,10 @@ __global__ __launch_bounds__(256) void macro_rank_kernel(const RenderParams p, i
 
 // Queue slot of tile t: macro tiles in rank order, PB_MACRO x macro_h slots each.
 PB_DI int tile_slot(const RenderParams& p, int t, int& m) {
-  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
+  const int mtx = (p.tiles_x + p.macro_w - 1) / p.macro_w;
   const int tx = t % p.tiles_x, tk = t / p.tiles_x;
-  m = (tk / p.macro_h) * mtx + tx / PB_MACRO;
-  return (int)p.macro_rank[m] * (PB_MACRO * p.macro_h) + (tk % p.macro_h) * PB_MACRO + tx % PB_MACRO;
+  m = (tk / p.macro_h) * mtx + tx / p.macro_w;
+  return (int)p.macro_rank[m] * (p.macro_w * p.macro_h) + (tk % p.macro_h) * p.macro_w + tx % p.macro_w;
 }
 
 // Items of a tile: the list of its macro tile cut into slices of p.slice, for each sub-sample group.
@@ -913,12 +921,13 @@ PB_DI void make_items_body(const RenderParams& p, int n_tiles, int t) {
   for (int q = 0; q < nsub; ++q) {
     if (p.group_last[t * nsub + q] < 0) continue;
     for (uint32_t c = 0; c < slices; ++c, ++it) {
-      if (it >= (uint32_t)p.item_capacity) return;
+      if (it >= (uint32_t)p.item_capacity) { if (p.tile_items) p.tile_items[t] = 0xffffffffu; return; }
       uint32_t* dst = p.items + (size_t)it * 4;
       const uint32_t n = (cnt - c * p.slice < (uint32_t)p.slice) ? cnt - c * p.slice : (uint32_t)p.slice;
       dst[0] = (uint32_t)(t * nsub + q); dst[1] = list0 + c * p.slice; dst[2] = n; dst[3] = 0u;
     }
   }
+  if (p.tile_items) p.tile_items[t] = it - p.item_off[slot];
 }
 
 __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, int n_tiles) {
@@ -981,7 +990,7 @@ __global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const Render
   __shared__ uint32_t s_cnt[256], s_inv[256], s_part[QUEUE_THREADS / 64];
   const int t = threadIdx.x;
   const int nsub = p.ssaa * p.ssaa;
-  const int mtx = (p.tiles_x + PB_MACRO - 1) / PB_MACRO;
+  const int mtx = (p.tiles_x + p.macro_w - 1) / p.macro_w;
   if (t < n_macro) {
     // list length of macro tile t = sum of the binning blocks' counts, each replaced by the sum of those before it
     uint32_t run = 0;
@@ -1007,7 +1016,7 @@ __global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const Render
     if (t == n_macro - 1) p.ctrl[2] = off + mine;
   }
   __syncthreads();
-  const int per_macro = PB_MACRO * p.macro_h;
+  const int per_macro = p.macro_w * p.macro_h;
   const int slots = n_macro * per_macro;
   const int per = (slots + QUEUE_THREADS - 1) / QUEUE_THREADS;
   const int slot0 = t * per;
@@ -1015,7 +1024,7 @@ __global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const Render
   auto slot_info = [&](int slot, uint32_t& cnt, uint32_t& m) -> int {
     m = s_inv[slot / per_macro];
     const int local = slot % per_macro;
-    const int tx = (int)(m % mtx) * PB_MACRO + local % PB_MACRO, tk = (int)(m / mtx) * p.macro_h + local / PB_MACRO;
+    const int tx = (int)(m % mtx) * p.macro_w + local % p.macro_w, tk = (int)(m / mtx) * p.macro_h + local / p.macro_w;
     cnt = s_cnt[m];
     return (tx < p.tiles_x && tk < p.tiles_y) ? tk * p.tiles_x + tx : -1;
   };
@@ -1235,6 +1244,7 @@ PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t 
   }
 }
 
+template <bool FINALIZE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_items_fast_kernel(const RenderParams p) {
   __shared__ uint32_t surv[PB_SLICE];
   const int lane = threadIdx.x;
@@ -1295,12 +1305,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     if (k < nb) pair_step(frames, ra, rb, off_cur, off_cur, r, extinction, sum);
   }
-  if (sum.nc) {
-    unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
-    const unsigned long long bias = (unsigned long long)sum.nc * magic_bits;
-    atomicAdd(&dst[0], sum.ai[0] + sum.ag - bias);
-    atomicAdd(&dst[64], sum.ai[1] + sum.ag - bias);
-    atomicAdd(&dst[128], sum.ai[2] + sum.ag - bias);
+  unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
+  if (!FINALIZE) {
+    if (sum.nc) {
+      const unsigned long long bias = (unsigned long long)sum.nc * magic_bits;
+      atomicAdd(&dst[0], sum.ai[0] + sum.ag - bias);
+      atomicAdd(&dst[64], sum.ai[1] + sum.ag - bias);
+      atomicAdd(&dst[128], sum.ai[2] + sum.ag - bias);
+    }
+  } else {
+    // The item that finds all the others of its tile done writes the tile's pixels.  Everything is exchanged through
+    // atomic read-modify-writes, which execute at the memory side whatever any cache holds, so no cache has to be
+    // written back or invalidated (an agent-scope release per item made this kernel fifteen times slower): the
+    // additions return their old values, the wave waits for them - the sums are then in place - and only then counts
+    // itself done; the wave that reads the full count fetches the sums by adding zero.
+    unsigned long long r0 = 0ull, r1 = 0ull, r2 = 0ull;
+    if (sum.nc) {
+      const unsigned long long bias = (unsigned long long)sum.nc * magic_bits;
+      r0 = atomicAdd(&dst[0], sum.ai[0] + sum.ag - bias);
+      r1 = atomicAdd(&dst[64], sum.ai[1] + sum.ag - bias);
+      r2 = atomicAdd(&dst[128], sum.ai[2] + sum.ag - bias);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
+    uint32_t before = 0u;
+    if (lane == 0) before = __hip_atomic_fetch_add(&p.tile_done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+    if (before + 1u == pb_uniform(p.tile_items)[tile]) {
+      asm volatile("" : : : "memory");
+      const unsigned long long v0 = atomicAdd(&dst[0], 0ull), v1 = atomicAdd(&dst[64], 0ull), v2 = atomicAdd(&dst[128], 0ull);
+      const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
+      const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
+      if (ox < p.out_w && oy < p.out_h) {
+        const double inv = PB_FIX_SCALE / (double)p.ssaa;      // skeleton.cpp:361: current / (double) SSAA
+        float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
+        o[0] = (float)((double)(long long)v0 * inv);
+        o[1] = (float)((double)(long long)v1 * inv);
+        o[2] = (float)((double)(long long)v2 * inv);
+      }
+    }
   }
 }
 
@@ -1468,6 +1510,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
 
 int pb_fused_queue_macros(void) { return QUEUE_FUSED_MACROS; }
 
+// Whether an uncounted frame of `mode` is evaluated by eval_items_fast_kernel (one wave per item, 32-bit record offsets).
+bool pb_pipelined_eval(const RenderParams& p, int mode) {
+  return mode == PB_MODE_721 && !p.precise && p.eval_waves <= 0 && (size_t)p.n_seg * sizeof(SegFrame) < ((size_t)1 << 31) &&
+         !std::getenv("PB_OLD_EVAL");
+}
+
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
   (void)mode;
   const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
@@ -1576,8 +1624,14 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
   else if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (p.precise) hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
-  else if (p.eval_waves <= 0 && (size_t)p.n_seg * sizeof(SegFrame) < ((size_t)1 << 31) && !std::getenv("PB_OLD_EVAL"))
-    hipLaunchKernelGGL(eval_items_fast_kernel, dim3(waves), dim3(64), 0, s, p);
+  else if (pb_pipelined_eval(p, mode)) {
+    if (p.finalize_in_eval) {
+      hipLaunchKernelGGL(eval_items_fast_kernel<true>, dim3(waves), dim3(64), 0, s, p);
+      PB_HIP(hipGetLastError());
+      return PB_OK;
+    }
+    hipLaunchKernelGGL(eval_items_fast_kernel<false>, dim3(waves), dim3(64), 0, s, p);
+  }
   else hipLaunchKernelGGL(eval_bins_fast_kernel, dim3(waves), dim3(64), 0, s, p);
   const size_t px = (size_t)p.out_w * p.out_h;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, p);

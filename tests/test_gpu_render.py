@@ -369,3 +369,33 @@ def test_short_view_rays(pb):
     for name, img in frames.items():
         assert np.abs(img - ref).max() <= 2e-5 + 1e-4 * ref.max(), name
     assert np.abs(fast - ref).max() <= 1e-4 * max(1.0, ref.max())
+
+
+@pytest.mark.parametrize("kw", [dict(screen_width=512, screen_height=512, photon_number=1000, bounces=0),
+                                dict(screen_width=200, screen_height=136, photon_number=600, bounces=2, ssaa=2)])
+def test_repeated_frames_of_one_segment_set_are_bit_identical(pb, kw):
+    """The first binned frame of a segment set sizes the workspace and leaves list offsets and the item queue in
+    it; the frames after it are three launches (ray set-up + list fill, evaluation whose last item per tile writes
+    the pixels).  Every such frame must equal the first one and the ordered scan path's radiance."""
+    import torch
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        W, H = kw["screen_width"], kw["screen_height"]
+        first = ctx.draw(cull="bins")
+        assert first.max() > 0
+        out = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        for k in range(30):
+            ctx.draw_device(out.data_ptr(), 0, 0, W, H, cull="bins", stream=stream)
+            if k % 10 == 9:
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy(), first), k
+                out.fill_(-1.0)
+        scan = ctx.draw(cull="scan")
+        assert np.abs(scan - first).max() <= 1e-6 * max(1.0, float(scan.max()))
+        # a part of the frame, then the whole again: each change of geometry sizes anew
+        part = ctx.draw(40, 24, 99, 77, cull="bins")
+        assert np.array_equal(part, first[24:24 + 77, 40:40 + 99])
+        assert np.array_equal(ctx.draw(cull="bins"), first)
+        assert np.array_equal(ctx.draw(cull="bins"), first)
