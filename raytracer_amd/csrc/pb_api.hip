@@ -376,6 +376,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   RenderParams p;
   std::memset(&p, 0, sizeof(p));
   p.tris = ctx->d_tris; p.n_tri = ctx->n_tri; p.tri_box = (const float4*)(ctx->d_tris + ctx->n_tri);
+  p.tri_edge = (const float*)(p.tri_box + ctx->n_tri);
   p.frames = ctx->d_frames; p.capA = ctx->d_capA; p.capB = ctx->d_capB; p.n_seg = ctx->n_seg;
   host_gate_setup(ctx->root_lo, ctx->root_hi, p.root);
   p.width = ctx->ctl.screen_width; p.height = ctx->ctl.screen_height; p.ssaa = ctx->ctl.ssaa;
@@ -399,6 +400,8 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   p.precise = ctx->precise ? 1 : 0;
   // a rank's share of interleaved strips has few items: shorter ones keep the longest wave short
   p.slice = ctx->tune_slice > 0 ? ctx->tune_slice : (strip_stride > 1 ? 96 : 128);   // render_binned refines it per frame geometry
+  p.slice_whole = 0;
+  if (const char* e = std::getenv("PB_TUNE_WHOLE")) { int v = std::atoi(e); if (v >= 0 && v <= PB_SLICE) p.slice_whole = v; }
   p.eval_waves = ctx->tune_waves;
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
@@ -544,10 +547,11 @@ int pb_set_scene(pb_ctx* ctx, const float* tri_xyz, int n_tri, const float matri
   if (ctx->d_tri_xyz) { PB_HIP(hipFree(ctx->d_tri_xyz)); ctx->d_tri_xyz = nullptr; }
   if (ctx->d_tris) { PB_HIP(hipFree(ctx->d_tris)); ctx->d_tris = nullptr; }
   PB_HIP(hipMalloc(&ctx->d_tri_xyz, sizeof(float) * 9 * (size_t)n_tri));
-  PB_HIP(hipMalloc(&ctx->d_tris, (sizeof(TriPrep) + sizeof(float4)) * (size_t)n_tri));
+  PB_HIP(hipMalloc(&ctx->d_tris, (sizeof(TriPrep) + sizeof(float4) + 12 * sizeof(float)) * (size_t)n_tri));
   PB_HIP(hipMemcpyAsync(ctx->d_tri_xyz, tri_xyz, sizeof(float) * 9 * (size_t)n_tri, hipMemcpyHostToDevice, ctx->stream));
   PB_HIP(hipMemcpyAsync(ctx->d_matrix, matrix, sizeof(float) * 16, hipMemcpyHostToDevice, ctx->stream));
-  rc = pb_launch_prepare_scene(ctx->d_tri_xyz, n_tri, ctx->d_matrix, ctx->d_tris, (float4*)(ctx->d_tris + n_tri), ctx->stream);
+  rc = pb_launch_prepare_scene(ctx->d_tri_xyz, n_tri, ctx->d_matrix, ctx->d_tris, (float4*)(ctx->d_tris + n_tri),
+                               (float*)((float4*)(ctx->d_tris + n_tri) + n_tri), ctx->stream);
   if (rc != PB_OK) return rc;
   PB_HIP(hipStreamSynchronize(ctx->stream));
   ctx->n_tri = n_tri;

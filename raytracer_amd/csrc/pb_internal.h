@@ -102,6 +102,7 @@ struct GateBox {
 struct RenderParams {
   const TriPrep* tris;
   const float4* tri_box;   // per triangle: bounds of x/z, y/z seen from the camera (lo, hi, lo, hi)
+  const float* tri_edge;   // per triangle 12 floats: its edges as lines a u + b v + c in the (x/z, y/z) plane, [9] = usable
   int n_tri;
   const SegFrame* frames;
   const float4* capA;      // (start.xyz, radius)
@@ -156,6 +157,7 @@ struct RenderParams {
   int fused_queue;          // 1: ray set-up clears the accumulators and one block builds the queue (small frames)
   int n_items_host;         // number of items of this frame as measured when the workspace was sized
   int slice;                // candidates of a macro list per evaluation item (<= PB_SLICE)
+  int slice_whole;          // a list of at most this many candidates is one item whatever `slice` (<= PB_SLICE; 0: none)
   int eval_waves;           // size of the persistent evaluation grid
   // LBVH (lbvh_n < 2: scan all segments)
   const LbvhNode* lbvh_nodes;
@@ -227,7 +229,7 @@ struct pb_ctx {
   // scene
   float* d_tri_xyz = nullptr;
   float* d_matrix = nullptr;
-  TriPrep* d_tris = nullptr;            // followed by n_tri float4 screen boxes
+  TriPrep* d_tris = nullptr;            // followed by n_tri float4 screen boxes and n_tri x 12 floats of screen edges
   int n_tri = 0;
   float matrix[16];
   // beams of the last pb_emit_beams: beams_const list, then beams_scattered list
@@ -299,7 +301,7 @@ int pb_lbvh_download(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes
 
 // launchers implemented in the kernel translation units
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matrix16, TriPrep* d_out,
-                            float4* d_screen_box, hipStream_t s);
+                            float4* d_screen_box, float* d_screen_edge, hipStream_t s);
 int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int one_dimensional, float scattering_c, SegFrame* d_frames,
                                float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s);
 int pb_launch_beam_axis(const float4* d_capA, const float4* d_capB, const HetFrame* d_het, int n, BeamAxis* d_out, hipStream_t s);
@@ -309,10 +311,14 @@ int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s);
 int pb_launch_bin_count(const RenderParams& p, bool count, hipStream_t s);
 int pb_fused_queue_macros(void);
 bool pb_pipelined_eval(const RenderParams& p, int mode);
-// Lane-per-macro-tile binning (pb_render.hip): segments per wave and blocks of 16 waves for a segment count.
-constexpr int PB_MBIN_WAVES = 16;
+// Lane-per-macro-tile binning (pb_render.hip): segments per wave and blocks of PB_MBIN_WAVES waves for a segment count.
+constexpr int PB_MBIN_WAVES = 4;
 PB_HDI int pb_mbin_spw(int n_seg) { return n_seg <= 4096 ? 4 : (n_seg <= 32768 ? 16 : 32); }
 PB_HDI int pb_mbin_blocks(int n_seg) { const int per = PB_MBIN_WAVES * pb_mbin_spw(n_seg); return (n_seg + per - 1) / per; }
+// Evaluation items a list of cnt candidates is cut into.
+PB_HDI uint32_t pb_item_slices(const RenderParams& p, uint32_t cnt) {
+  return cnt <= (uint32_t)p.slice_whole ? (cnt ? 1u : 0u) : (cnt + (uint32_t)p.slice - 1u) / (uint32_t)p.slice;
+}
 PB_HDI int pb_macro_count(const RenderParams& p) {
   return ((p.tiles_x + p.macro_w - 1) / p.macro_w) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
 }

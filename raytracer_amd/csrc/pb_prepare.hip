@@ -8,7 +8,7 @@
 // ClosestIntersection, Intersections.h:468-476: v = matrix * triangle vertex,
 // e1 = v1 - v0, e2 = v2 - v0, and the cofactors of columns 1,2 of A = (-dir,e1,e2).
 __global__ void prepare_scene_kernel(const float* __restrict__ tri_xyz, int n_tri, const float* __restrict__ matrix,
-                                     TriPrep* __restrict__ out, float4* __restrict__ screen_box) {
+                                     TriPrep* __restrict__ out, float4* __restrict__ screen_box, float* __restrict__ screen_edge) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_tri) return;
   float m[16];
@@ -42,6 +42,29 @@ __global__ void prepare_scene_kernel(const float* __restrict__ tri_xyz, int n_tr
                      fminf(w0, fminf(w1, w2)) - m, fmaxf(w0, fmaxf(w1, w2)) + m);
   }
   screen_box[i] = sb;
+  // The triangle's three edges as lines in the same (x/z, y/z) plane (a perspective view keeps lines straight):
+  // a u + b v + c = distance from the edge, positive on the side of the third vertex.  A tile whose rectangle lies
+  // more than a margin outside one edge cannot hold a ray that satisfies the barycentric tests.  [9] = 1 if usable.
+  float e[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (v0.z > 0.05f && v1.z > 0.05f && v2.z > 0.05f) {
+    const float u[3] = {v0.x / v0.z, v1.x / v1.z, v2.x / v2.z};
+    const float w[3] = {v0.y / v0.z, v1.y / v1.z, v2.y / v2.z};
+    bool ok = true;
+    for (int k = 0; k < 3; ++k) {
+      const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+      float a = w[k1] - w[k], b = -(u[k1] - u[k]);
+      const float len = sqrtf(a * a + b * b);
+      if (!(len > 1e-6f)) { ok = false; break; }
+      a /= len; b /= len;
+      float c = -(a * u[k] + b * w[k]);
+      const float third = a * u[k2] + b * w[k2] + c;
+      if (fabsf(third) < 1e-5f) { ok = false; break; }        // seen edge-on: no inside to speak of
+      if (third < 0) { a = -a; b = -b; c = -c; }
+      e[3 * k] = a; e[3 * k + 1] = b; e[3 * k + 2] = c;
+    }
+    e[9] = ok ? 1.0f : 0.0f;
+  }
+  for (int k = 0; k < 12; ++k) screen_edge[(size_t)i * 12 + k] = e[k];
 }
 
 // findRotationMatrix, Intersections.h:499-513.
@@ -189,9 +212,9 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
 }
 
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_matrix16, TriPrep* d_out,
-                            float4* d_screen_box, hipStream_t s) {
+                            float4* d_screen_box, float* d_screen_edge, hipStream_t s) {
   hipLaunchKernelGGL(prepare_scene_kernel, dim3((n_tri + 63) / 64), dim3(64), 0, s, d_tri_xyz, n_tri, d_matrix16, d_out,
-                     d_screen_box);
+                     d_screen_box, d_screen_edge);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }

@@ -488,8 +488,8 @@ __global__ __launch_bounds__(64) void reduce_kernel(const RenderParams p) {
 // for bit.
 // ---------------------------------------------------------------------------
 // tris / tri_box: the prepared scene in global memory, or the copy the launch staged in LDS.
-template <bool COUNT, class TriPtr, class BoxPtr>
-PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tris, BoxPtr tri_box) {
+template <bool COUNT, class TriPtr, class BoxPtr, class EdgePtr>
+PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tris, BoxPtr tri_box, EdgePtr tri_edge) {
   const int nsub = p.ssaa * p.ssaa;
   const int tile = group / nsub, sub = group % nsub;
   const int si = sub / p.ssaa, sj = sub % p.ssaa;
@@ -526,6 +526,17 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
       const float m = 1e-4f * p.focal;           // the screen boxes are in units of x / z, the rays' z is focal
       may = !(x_hi < sb_x * p.focal - m * (1.0f + fabsf(sb_x)) || x_lo > sb_y * p.focal + m * (1.0f + fabsf(sb_y)) ||
               y_hi < sb_z * p.focal - m * (1.0f + fabsf(sb_z)) || y_lo > sb_w * p.focal + m * (1.0f + fabsf(sb_w)));
+      // the tile's rectangle against the triangle's own edges (its screen box is much larger than a wall's half)
+      if (tri_edge[12 * lane + 9] != 0.0f) {
+        const float inv_f = 1.0f / p.focal;
+        const float u_lo = x_lo * inv_f, u_hi = x_hi * inv_f, v_lo = y_lo * inv_f, v_hi = y_hi * inv_f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float a = tri_edge[12 * lane + 3 * k], b = tri_edge[12 * lane + 3 * k + 1], c = tri_edge[12 * lane + 3 * k + 2];
+          const float farthest_in = a * (a >= 0.0f ? u_hi : u_lo) + b * (b >= 0.0f ? v_hi : v_lo) + c;
+          may = may && !(farthest_in < -2e-3f);
+        }
+      }
     }
     tri_mask = __ballot(may);
   }
@@ -569,7 +580,7 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
 
 template <bool COUNT>
 __global__ __launch_bounds__(64) void ray_setup_kernel(const RenderParams p) {
-  ray_setup_body<COUNT>(p, blockIdx.x, threadIdx.x, p.tris, p.tri_box);
+  ray_setup_body<COUNT>(p, blockIdx.x, threadIdx.x, p.tris, p.tri_box, p.tri_edge);
 }
 
 // Inward unit normals of the side planes of the pyramid spanned by the sub-rays of the pixel rectangle
@@ -905,14 +916,15 @@ __global__ __launch_bounds__(256) void tile_items_kernel(const RenderParams p, i
   p.tile_count[t] = cnt;
   uint32_t n_items = 0;
   for (int q = 0; q < nsub; ++q)
-    if (p.group_last[t * nsub + q] >= 0) n_items += (cnt + p.slice - 1) / p.slice;
+    if (p.group_last[t * nsub + q] >= 0) n_items += pb_item_slices(p, cnt);
   p.item_off[slot] = n_items;
 }
 
 PB_DI void make_items_body(const RenderParams& p, int n_tiles, int t) {
   if (t >= n_tiles) return;
   const uint32_t cnt = p.tile_count[t];
-  const uint32_t slices = (cnt + p.slice - 1) / p.slice;
+  const uint32_t slices = pb_item_slices(p, cnt);
+  const uint32_t len = cnt <= (uint32_t)p.slice_whole ? cnt : (uint32_t)p.slice;
   const int nsub = p.ssaa * p.ssaa;
   int m;
   const int slot = tile_slot(p, t, m);
@@ -923,8 +935,8 @@ PB_DI void make_items_body(const RenderParams& p, int n_tiles, int t) {
     for (uint32_t c = 0; c < slices; ++c, ++it) {
       if (it >= (uint32_t)p.item_capacity) { if (p.tile_items) p.tile_items[t] = 0xffffffffu; return; }
       uint32_t* dst = p.items + (size_t)it * 4;
-      const uint32_t n = (cnt - c * p.slice < (uint32_t)p.slice) ? cnt - c * p.slice : (uint32_t)p.slice;
-      dst[0] = (uint32_t)(t * nsub + q); dst[1] = list0 + c * p.slice; dst[2] = n; dst[3] = 0u;
+      const uint32_t n = (cnt - c * len < len) ? cnt - c * len : len;
+      dst[0] = (uint32_t)(t * nsub + q); dst[1] = list0 + c * len; dst[2] = n; dst[3] = 0u;
     }
   }
   if (p.tile_items) p.tile_items[t] = it - p.item_off[slot];
@@ -938,8 +950,9 @@ __global__ __launch_bounds__(256) void make_items_kernel(const RenderParams p, i
 // a launch with a step that does not depend on them.  Blocks [0, bin_blocks) bin; the others set up rays,
 // one ray group per wave (count pass), or write the evaluation items (fill pass).
 constexpr int ITEM_LANES = 64;
-// Ray set-up of a 1024-thread block: sixteen ray groups, one per wave.  The prepared triangles and their screen
-// boxes (80 bytes per triangle, adjacent in memory) are first copied to LDS by the whole block in one round trip:
+// Ray set-up of a block of MBIN_WAVES waves: one ray group per wave (blocks of sixteen waves, one per compute unit,
+// left nothing to overlap a block's staging and store drain with: 16.0 -> 13.6 us at four).  The prepared triangles and their screen
+// boxes and edges (128 bytes per triangle, adjacent in memory) are first copied to LDS by the whole block in one round trip:
 // read one triangle at a time through the scalar unit, a wave paid a dependent trip to L2 for every triangle its
 // tile can see.
 constexpr int SCENE_LDS_MAX_TRI = 256;
@@ -948,19 +961,20 @@ PB_DI void ray_role(const RenderParams& p, uint32_t* lds, int ray_block, int gro
   typedef __attribute__((address_space(3))) float LdsFloat;
   typedef __attribute__((address_space(3))) Box4 LdsBox4;
   typedef __attribute__((address_space(3))) TriPrep LdsTriPrep;
-  const int group = ray_block * (BIN_THREADS / 64) + (int)(threadIdx.x >> 6);
+  const int group = ray_block * (MBIN_THREADS / 64) + (int)(threadIdx.x >> 6);
   if (scene_in_lds) {
     LdsFloat* dst = (LdsFloat*)lds;
-    const float* src = (const float*)p.tris;            // n_tri TriPrep records (16 floats), then n_tri screen boxes (4)
-    for (int i = threadIdx.x; i < p.n_tri * 20; i += BIN_THREADS) dst[i] = src[i];
+    const float* src = (const float*)p.tris;            // n_tri TriPrep records (16 floats), screen boxes (4), screen edges (12)
+    for (int i = threadIdx.x; i < p.n_tri * 32; i += MBIN_THREADS) dst[i] = src[i];
     __syncthreads();
     if (group < groups)
-      ray_setup_body<false>(p, group, threadIdx.x & 63, (const LdsTriPrep*)lds, (const LdsBox4*)lds + 4 * p.n_tri);
+      ray_setup_body<false>(p, group, threadIdx.x & 63, (const LdsTriPrep*)lds, (const LdsBox4*)lds + 4 * p.n_tri,
+                            (const LdsFloat*)lds + 20 * p.n_tri);
   } else if (group < groups) {
-    ray_setup_body<false>(p, group, threadIdx.x & 63, p.tris, p.tri_box);
+    ray_setup_body<false>(p, group, threadIdx.x & 63, p.tris, p.tri_box, p.tri_edge);
   }
 }
-__global__ __launch_bounds__(BIN_THREADS) void setup_count_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups, int scene_in_lds) {
+__global__ __launch_bounds__(MBIN_THREADS) void setup_count_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups, int scene_in_lds) {
   extern __shared__ __align__(16) uint32_t bin_lds[];
   if ((int)blockIdx.x < bin_blocks) { macro_bin_body<false>(p, n_macro, bin_lds, blockIdx.x); return; }
   ray_role(p, bin_lds, (int)blockIdx.x - bin_blocks, groups, scene_in_lds);
@@ -968,13 +982,13 @@ __global__ __launch_bounds__(BIN_THREADS) void setup_count_kernel(const RenderPa
 
 // A frame whose list offsets and evaluation items are in place (kept from the frame that sized the workspace for this
 // segment set and frame geometry): ray set-up beside the one binning pass it needs, the fill.
-__global__ __launch_bounds__(BIN_THREADS) void setup_fill_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups, int scene_in_lds) {
+__global__ __launch_bounds__(MBIN_THREADS) void setup_fill_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups, int scene_in_lds) {
   extern __shared__ __align__(16) uint32_t bin_lds[];
   if ((int)blockIdx.x < bin_blocks) { macro_bin_body<true>(p, n_macro, bin_lds, blockIdx.x); return; }
   ray_role(p, bin_lds, (int)blockIdx.x - bin_blocks, groups, scene_in_lds);
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void fill_items_kernel(const RenderParams p, int n_macro, int bin_blocks, int n_tiles) {
+__global__ __launch_bounds__(MBIN_THREADS) void fill_items_kernel(const RenderParams p, int n_macro, int bin_blocks, int n_tiles) {
   extern __shared__ uint32_t bin_lds[];
   if ((int)blockIdx.x < bin_blocks) { macro_bin_body<true>(p, n_macro, bin_lds, blockIdx.x); return; }
   // one wave per block writes items: spread over many compute units, the scattered 16-byte stores of four
@@ -1033,7 +1047,7 @@ __global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const Render
     uint32_t cnt, m;
     const int tile = slot_info(slot, cnt, m);
     if (tile < 0) continue;
-    const uint32_t slices = (cnt + p.slice - 1) / p.slice;
+    const uint32_t slices = pb_item_slices(p, cnt);
     for (int q = 0; q < nsub; ++q)
       if (p.group_last[tile * nsub + q] >= 0) mine_items += slices;
   }
@@ -1060,7 +1074,7 @@ __global__ __launch_bounds__(QUEUE_THREADS) void queue_build_kernel(const Render
     p.item_off[slot] = it;
     if (tile < 0) continue;
     p.tile_count[tile] = cnt;
-    const uint32_t slices = (cnt + p.slice - 1) / p.slice;
+    const uint32_t slices = pb_item_slices(p, cnt);
     for (int q = 0; q < nsub; ++q)
       if (p.group_last[tile * nsub + q] >= 0) it += slices;
   }
@@ -1561,10 +1575,10 @@ int pb_launch_ray_setup(const RenderParams& p, bool count, hipStream_t s) {
   if (shares_launches(p, count)) {
     const int n_macro = pb_macro_count(p);
     const int bin_blocks = pb_mbin_blocks(p.n_seg);
-    const int ray_blocks = (groups + BIN_THREADS / 64 - 1) / (BIN_THREADS / 64);
+    const int ray_blocks = (groups + MBIN_THREADS / 64 - 1) / (MBIN_THREADS / 64);
     const int scene_in_lds = p.n_tri <= SCENE_LDS_MAX_TRI ? 1 : 0;
-    const size_t lds = std::max(pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)80 * p.n_tri : (size_t)0);
-    hipLaunchKernelGGL(setup_count_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), lds, s,
+    const size_t lds = std::max(pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)128 * p.n_tri : (size_t)0);
+    hipLaunchKernelGGL(setup_count_kernel, dim3(bin_blocks + ray_blocks), dim3(MBIN_THREADS), lds, s,
                        p, n_macro, bin_blocks, groups, scene_in_lds);
     PB_HIP(hipGetLastError());
     return PB_OK;
@@ -1646,7 +1660,7 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
     const int n_macro = pb_macro_count(p);
     const int bin_blocks = pb_mbin_blocks(p.n_seg);
     const int item_blocks = (tiles + ITEM_LANES - 1) / ITEM_LANES;
-    hipLaunchKernelGGL(fill_items_kernel, dim3(bin_blocks + item_blocks), dim3(BIN_THREADS), pb_mbin_lds_bytes(n_macro), s,
+    hipLaunchKernelGGL(fill_items_kernel, dim3(bin_blocks + item_blocks), dim3(MBIN_THREADS), pb_mbin_lds_bytes(n_macro), s,
                        p, n_macro, bin_blocks, tiles);
   } else {
     if (p.n_seg > 0) launch_bin_pass<true>(p, pb_macro_count(p), s);
@@ -1662,10 +1676,10 @@ int pb_launch_fast_frame(const RenderParams& p, int mode, hipStream_t s) {
   if (groups <= 0) return PB_OK;
   const int n_macro = pb_macro_count(p);
   const int bin_blocks = pb_mbin_blocks(p.n_seg);
-  const int ray_blocks = (groups + BIN_THREADS / 64 - 1) / (BIN_THREADS / 64);
+  const int ray_blocks = (groups + MBIN_THREADS / 64 - 1) / (MBIN_THREADS / 64);
   const int scene_in_lds = p.n_tri <= SCENE_LDS_MAX_TRI ? 1 : 0;
-  const size_t lds = std::max(pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)80 * p.n_tri : (size_t)0);
-  hipLaunchKernelGGL(setup_fill_kernel, dim3(bin_blocks + ray_blocks), dim3(BIN_THREADS), lds, s,
+  const size_t lds = std::max(pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)128 * p.n_tri : (size_t)0);
+  hipLaunchKernelGGL(setup_fill_kernel, dim3(bin_blocks + ray_blocks), dim3(MBIN_THREADS), lds, s,
                      p, n_macro, bin_blocks, groups, scene_in_lds);
   return launch_eval_finalize(p, mode, false, s);
 }
