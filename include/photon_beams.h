@@ -209,7 +209,10 @@ int pb_download_beams(pb_ctx* ctx, pb_beam* out, int capacity, int* n_out);  /* 
 int pb_beam_counts(pb_ctx* ctx, int* n_const, int* n_scattered);
 
 /* BuildTree (CastPhotons.h:800-1126) replacement: Morton codes of the segment
- * midpoints, LDS radix sort, Karras hierarchy, bottom-up refit. */
+ * midpoints, LDS radix sort, Karras hierarchy, node boxes from tabulated unions over each node's
+ * range of the sorted order.  The kernels are queued on the context's own stream and not waited for; render calls
+ * that traverse the tree on another stream wait for them there.  A build of a segment set that fits the buffers of an
+ * earlier one allocates nothing. */
 int pb_build_lbvh(pb_ctx* ctx);
 /* keys[n], perm[n], nodes[n-1] (any may be NULL). */
 int pb_download_lbvh(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes);

@@ -394,6 +394,8 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   p.tiles_x = (out_w + 7) / 8; p.tiles_y = (out_h + 7) / 8;
   p.out = d_out;
   if (use_lbvh == 1 && ctx->lb_n >= 2) {
+    // the build was queued on the context's stream and not waited for
+    if (s != ctx->stream) PB_HIP(hipStreamWaitEvent(s, ctx->ev[5], 0));
     p.lbvh_nodes = ctx->lb_nodes; p.lbvh_sA = ctx->lb_sA; p.lbvh_sB = ctx->lb_sB; p.lbvh_perm = ctx->lb_perm;
     p.lbvh_n = ctx->lb_n;
   }
@@ -520,8 +522,7 @@ void pb_destroy(pb_ctx* ctx) {
                   ctx->d_het, ctx->d_het_axis, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
                   ctx->d_emit_tmp[1], ctx->ws.d_rays, ctx->ws.d_group_last,
                   ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list, ctx->ws.d_blk,
-                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes,
-                  ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right, ctx->lb_node_box, ctx->lb_leaf_box};
+                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->lb_pool};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);

@@ -267,6 +267,10 @@ struct pb_ctx {
   int* lb_right = nullptr;
   float* lb_node_box = nullptr;
   float* lb_leaf_box = nullptr;
+  void* lb_pool = nullptr;                 // the one allocation all of the above and the build's scratch live in
+  size_t lb_cap = 0;                       // segments it is laid out for
+  uint64_t* lb_keys2 = nullptr; uint32_t* lb_vals2 = nullptr; uint32_t* lb_hist = nullptr; uint32_t* lb_scan_tmp = nullptr;
+  int* lb_range_lo = nullptr; int* lb_range_hi = nullptr; float* lb_unions = nullptr; uint32_t* lb_bounds = nullptr;
   int lb_n = -1;
   unsigned long long lb_version = ~0ull;
   // frame workspace: grown on demand by this context's render calls

@@ -6,11 +6,18 @@
 //      a device-wide exclusive scan of (digit, block) counts, and a stable
 //      scatter whose in-block ranks come from wave match masks and per-wave LDS
 //      counters (no atomics on the rank path, so the permutation is stable)
+//      (up to 64 sort blocks, 131 072 segments, every scatter block sums the block
+//      histograms itself: two launches per pass instead of five)
 //   4. Karras (2012) hierarchy: one lane per internal node, ties between equal
 //      keys broken by sorted position
-//   5. bottom-up refit with one arrival counter per internal node
+//   5. node boxes from range tables: a node's box is the union of the leaf boxes
+//      over its range of the sorted order, covered by tabulated unions of 64,
+//      64^2, ... leaves (no bottom-up walk, no arrival counters)
 //   6. packing: each internal node record carries both child boxes, leaves are
 //      the sorted capsules
+// All buffers live in one allocation that grows with the segment count and is kept
+// between builds; a build of a set that fits allocates nothing and does not wait for
+// the device.
 // The reference's tree decides nothing about the result except through the gate
 // boxes stored with each segment; this structure only finds candidates.
 #include <cstring>
@@ -37,6 +44,10 @@ PB_HDI float ord_float(uint32_t o) {
   float f;
   memcpy(&f, &u, sizeof(f));
   return f;
+}
+
+__global__ void bounds_init_kernel(uint32_t* __restrict__ bounds6) {
+  if (threadIdx.x < 6) bounds6[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
 }
 
 __global__ __launch_bounds__(256) void bounds_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
@@ -117,6 +128,9 @@ PB_DI unsigned long long match_digit(uint32_t digit, bool valid) {
   return peers;
 }
 
+// SCANNED: gscan holds the device-wide exclusive scan of the (digit, block) counts.  Otherwise it holds the counts
+// themselves and every block sums what lies before its own (few blocks: cheaper than three scan launches per pass).
+template <bool SCANNED>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in, int n,
                                                                    int shift, int n_blocks,
@@ -127,7 +141,25 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   __shared__ uint32_t goff[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
-  goff[threadIdx.x] = gscan[(size_t)threadIdx.x * n_blocks + blockIdx.x];
+  if (SCANNED) {
+    goff[threadIdx.x] = gscan[(size_t)threadIdx.x * n_blocks + blockIdx.x];
+  } else {
+    // keys with digit d go after all keys with smaller digits and after the keys with digit d of earlier blocks
+    static_assert(SORT_THREADS == 256, "one thread per digit");
+    const uint32_t* row = gscan + (size_t)threadIdx.x * n_blocks;
+    uint32_t total = 0, before = 0;
+    for (int b = 0; b < n_blocks; ++b) { const uint32_t c = row[b]; before += (b < (int)blockIdx.x) ? c : 0u; total += c; }
+    // exclusive scan of `total` over the 256 digits: in-wave shuffles, then the four wave sums
+    uint32_t incl = total;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) cnt[0][wave] = incl;       // cnt[0][0..3] borrowed; cleared again below
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += cnt[0][w];
+    __syncthreads();
+    if (threadIdx.x < SORT_WAVES) cnt[0][threadIdx.x] = 0;
+    goff[threadIdx.x] = base + incl - total + before;
+  }
   __syncthreads();
   // wave w owns the contiguous keys [base + w*64*ITEMS, +64*ITEMS): order (wave, item, lane) = input order
   const int wbase = blockIdx.x * SORT_TILE + wave * 64 * SORT_ITEMS;
@@ -311,60 +343,74 @@ __global__ __launch_bounds__(256) void pack_kernel(const float4* __restrict__ ca
   }
 }
 
-struct Scratch {
-  void* p = nullptr;
-  ~Scratch() { if (p) (void)hipFree(p); }
-};
+constexpr int SORT_LOCAL_SUMS_MAX_BLOCKS = 64;     // up to here a scatter block sums the block histograms itself
+
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 }  // namespace
 
+// All of the build's memory is one allocation (ctx->lb_pool), laid out for a capacity of segments: the results the
+// traversal and pb_download_lbvh read, then the scratch of the build.  It grows (free + allocate, which waits for the
+// device) only when a segment set exceeds the capacity; otherwise a build allocates nothing and returns as soon as
+// its kernels are queued on the context's stream.  ctx->ev[5] marks the end of the last build: calls that read the
+// tree on another stream wait for it there.
 int pb_lbvh_build(pb_ctx* ctx) {
   const int n = ctx->n_seg;
   hipStream_t s = ctx->stream;
   PB_HIP(hipEventRecord(ctx->ev[4], s));
-  // persistent results
-  void* olds[] = {ctx->lb_keys, ctx->lb_perm, ctx->lb_nodes, ctx->lb_sA, ctx->lb_sB, ctx->lb_left, ctx->lb_right,
-                  ctx->lb_node_box, ctx->lb_leaf_box};
-  for (void* o : olds) if (o) PB_HIP(hipFree(o));
-  ctx->lb_keys = nullptr; ctx->lb_perm = nullptr; ctx->lb_nodes = nullptr; ctx->lb_sA = nullptr; ctx->lb_sB = nullptr;
-  ctx->lb_left = nullptr; ctx->lb_right = nullptr; ctx->lb_node_box = nullptr; ctx->lb_leaf_box = nullptr;
-  ctx->lb_n = 0;
   if (n < 2) {   // nothing to build: the renderer scans the (at most one) segment
     ctx->lb_n = n; ctx->lb_version = ctx->segs_version;
     PB_HIP(hipEventRecord(ctx->ev[5], s));
     ctx->ev_valid[2] = true;
     return PB_OK;
   }
-  const size_t N = (size_t)n;
-  PB_HIP(hipMalloc(&ctx->lb_keys, sizeof(uint64_t) * N));
-  PB_HIP(hipMalloc(&ctx->lb_perm, sizeof(uint32_t) * N));
-  PB_HIP(hipMalloc(&ctx->lb_nodes, sizeof(LbvhNode) * (N - 1)));
-  PB_HIP(hipMalloc(&ctx->lb_sA, sizeof(float4) * N));
-  PB_HIP(hipMalloc(&ctx->lb_sB, sizeof(float4) * N));
-  PB_HIP(hipMalloc(&ctx->lb_left, sizeof(int) * (N - 1)));
-  PB_HIP(hipMalloc(&ctx->lb_right, sizeof(int) * (N - 1)));
-  PB_HIP(hipMalloc(&ctx->lb_node_box, sizeof(float) * 6 * (N - 1)));
-  PB_HIP(hipMalloc(&ctx->lb_leaf_box, sizeof(float) * 6 * N));
-
+  if ((size_t)n > ctx->lb_cap) {
+    if (ctx->lb_pool) PB_HIP(hipFree(ctx->lb_pool));
+    ctx->lb_pool = nullptr; ctx->lb_cap = 0; ctx->lb_n = -1;
+    const size_t C = (size_t)n + (size_t)n / 8 + 64;
+    const size_t cap_blocks = (C + SORT_TILE - 1) / SORT_TILE;
+    const size_t hist_words = 256 * cap_blocks;
+    const size_t sizes[] = {
+        sizeof(uint64_t) * C,            // keys
+        sizeof(uint32_t) * C,            // perm
+        sizeof(LbvhNode) * C,            // nodes
+        sizeof(float4) * C, sizeof(float4) * C,        // sA, sB
+        sizeof(int) * C, sizeof(int) * C,              // left, right
+        sizeof(float) * 6 * C, sizeof(float) * 6 * C,  // node_box, leaf_box
+        sizeof(uint64_t) * C, sizeof(uint32_t) * C,    // scratch: keys2, vals2
+        sizeof(uint32_t) * hist_words,                 // (digit, block) histograms
+        sizeof(uint32_t) * (pb_scan_tmp_words((int)hist_words) + 8),   // scan scratch, total
+        sizeof(int) * C, sizeof(int) * C,              // range_lo, range_hi
+        sizeof(float) * C,                             // unions of 64, 64^2, ... leaf boxes: 6 (C/64 + C/4096 + ...) < 0.1 C floats
+        256};                                          // bounds of the midpoints
+    size_t total = 0;
+    for (size_t b : sizes) total += align256(b);
+    PB_HIP(hipMalloc(&ctx->lb_pool, total));
+    unsigned char* at = (unsigned char*)ctx->lb_pool;
+    auto take = [&](size_t bytes) { unsigned char* r = at; at += align256(bytes); return (void*)r; };
+    ctx->lb_keys = (uint64_t*)take(sizes[0]); ctx->lb_perm = (uint32_t*)take(sizes[1]); ctx->lb_nodes = (LbvhNode*)take(sizes[2]);
+    ctx->lb_sA = (float4*)take(sizes[3]); ctx->lb_sB = (float4*)take(sizes[4]);
+    ctx->lb_left = (int*)take(sizes[5]); ctx->lb_right = (int*)take(sizes[6]);
+    ctx->lb_node_box = (float*)take(sizes[7]); ctx->lb_leaf_box = (float*)take(sizes[8]);
+    ctx->lb_keys2 = (uint64_t*)take(sizes[9]); ctx->lb_vals2 = (uint32_t*)take(sizes[10]);
+    ctx->lb_hist = (uint32_t*)take(sizes[11]); ctx->lb_scan_tmp = (uint32_t*)take(sizes[12]);
+    ctx->lb_range_lo = (int*)take(sizes[13]); ctx->lb_range_hi = (int*)take(sizes[14]);
+    ctx->lb_unions = (float*)take(sizes[15]); ctx->lb_bounds = (uint32_t*)take(sizes[16]);
+    ctx->lb_cap = C;
+  }
   const int n_blocks = (n + SORT_TILE - 1) / SORT_TILE;
   const size_t hist_words = (size_t)256 * n_blocks;
-  const size_t scan_words = pb_scan_tmp_words((int)hist_words);
-  Scratch sc;
-  // keys2[N] (u64) | vals2[N] | hist[256*nb] | scan tmp | total | ranges (2N) | box unions (N words) | bounds (8)
-  const size_t bytes = sizeof(uint64_t) * N + sizeof(uint32_t) * (N + hist_words + scan_words + 8 + 2 * N + N + 8);
-  PB_HIP(hipMalloc(&sc.p, bytes));
-  uint64_t* keys2 = (uint64_t*)sc.p;
-  uint32_t* vals2 = (uint32_t*)(keys2 + N);
-  uint32_t* hist = vals2 + N;
-  uint32_t* scan_tmp = hist + hist_words;
-  uint32_t* total = scan_tmp + scan_words;
-  int* range_lo = (int*)(total + 8);
-  int* range_hi = range_lo + N;
-  float* unions = (float*)(range_hi + N);      // 6 (N/64 + N/4096 + ...) floats: below 0.1 N for N >= 64
-  uint32_t* bounds = (uint32_t*)(unions + N);
+  uint64_t* keys2 = ctx->lb_keys2;
+  uint32_t* vals2 = ctx->lb_vals2;
+  uint32_t* hist = ctx->lb_hist;
+  uint32_t* scan_tmp = ctx->lb_scan_tmp;
+  uint32_t* total = scan_tmp + pb_scan_tmp_words((int)hist_words);
+  int* range_lo = ctx->lb_range_lo;
+  int* range_hi = ctx->lb_range_hi;
+  float* unions = ctx->lb_unions;
+  uint32_t* bounds = ctx->lb_bounds;
 
-  const uint32_t init_bounds[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-  PB_HIP(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(64), 0, s, bounds);
   int bblocks = (n + 255) / 256;
   if (bblocks > 1024) bblocks = 1024;
   hipLaunchKernelGGL(bounds_kernel, dim3(bblocks), dim3(256), 0, s, ctx->d_capA, ctx->d_capB, n, bounds);
@@ -376,10 +422,15 @@ int pb_lbvh_build(pb_ctx* ctx) {
   for (int pass = 0; pass < SORT_PASSES; ++pass) {
     const int shift = 8 * pass;
     hipLaunchKernelGGL(sort_hist_kernel, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, n, shift, n_blocks, hist);
-    int rc = pb_exclusive_scan_u32(hist, hist, (int)hist_words, total, scan_tmp, s);
-    if (rc != PB_OK) return rc;
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift, n_blocks, hist,
-                       kout, vout);
+    if (n_blocks <= SORT_LOCAL_SUMS_MAX_BLOCKS) {
+      hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift, n_blocks, hist,
+                         kout, vout);
+    } else {
+      int rc = pb_exclusive_scan_u32(hist, hist, (int)hist_words, total, scan_tmp, s);
+      if (rc != PB_OK) return rc;
+      hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift, n_blocks, hist,
+                         kout, vout);
+    }
     PB_HIP(hipGetLastError());
     uint64_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
@@ -410,7 +461,6 @@ int pb_lbvh_build(pb_ctx* ctx) {
   PB_HIP(hipGetLastError());
   PB_HIP(hipEventRecord(ctx->ev[5], s));
   ctx->ev_valid[2] = true;
-  PB_HIP(hipStreamSynchronize(s));
   ctx->lb_n = n;
   ctx->lb_version = ctx->segs_version;
   return PB_OK;
