@@ -3,6 +3,8 @@
 // screenshot.bmp written headless.
 //   ./skeleton_headless [photons] [bounces] [width] [out.bmp] [het]
 //   ./skeleton_headless analysis      RUN_ANALYSIS (skeleton.cpp:82-84): NSD.csv and rRMSE.csv, no frame
+//   ./skeleton_headless segments <file> [out.bmp]   DrawStandard over a dumped segment set instead of a photon pass
+//                                      (tests/golden/cfg1_tree_segments.bin gives the reference's own screenshot)
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +18,23 @@ using namespace pbhost;
 int main(int argc, char** argv) {
   if (argc > 1 && std::strcmp(argv[1], "analysis") == 0) {
     try { RunAnalysis(); Shutdown(); } catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
+    return 0;
+  }
+  if (argc > 2 && std::strcmp(argv[1], "segments") == 0) {
+    try {
+      std::vector<Triangle> triangles;
+      LoadTestModel(triangles);
+      mat4 matrix;
+      TransformationMatrix(matrix);
+      std::vector<PhotonBeam> none;
+      LoadSegments(argv[2], matrix, triangles);
+      screen* scr = InitializeSDL(control.screen_width, control.screen_height, false);
+      DrawStandard(scr, none, none);
+      SDL_Renderframe(scr);
+      SDL_SaveImage(scr, argc > 3 ? argv[3] : "screenshot.bmp");
+      KillSDL(scr);
+      Shutdown();
+    } catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
     return 0;
   }
   if (argc > 1) control.photon_number = std::atoi(argv[1]);

@@ -193,6 +193,18 @@ int pb_segment_count(pb_ctx* ctx, int* n_out);
 int pb_download_segments(pb_ctx* ctx, pb_segment* out, int capacity, int* n_out);
 int pb_get_root_box(pb_ctx* ctx, float root_lo[3], float root_hi[3]);
 
+/* The segment set on disk: a 64-byte header ("PBSEGS\0\1", version 1, record size 112, count, root box) followed by
+ * the pb_segment records (layout: raytracer_amd/csrc/pb_file.cpp).  It stands where the reference would hand
+ * `segments` (CastPhotons.h:83) from one run to the next: a set dumped from one host - the reference's own tree
+ * segments with their leaf boxes, say - renders on another without repeating the photon pass, and the same file is
+ * the checkpoint of a stop-motion run.  The two file functions are host code and need no GPU; pb_save_segments
+ * writes the context's current set and root box, pb_load_segments is pb_upload_segments from a file. */
+int pb_write_segments_file(const char* path, const pb_segment* segs, int n, const float root_lo[3], const float root_hi[3]);
+/* out may be NULL to ask for the count (and the root box) only. */
+int pb_read_segments_file(const char* path, pb_segment* out, int capacity, int* n_out, float root_lo[3], float root_hi[3]);
+int pb_save_segments(pb_ctx* ctx, const char* path);
+int pb_load_segments(pb_ctx* ctx, const char* path);
+
 /* CastPhotonBeams (CastPhotons.h:312-390) + BoundPhotonBeams (:144-288) on the
  * GPU: one photon per lane, counter-based random numbers keyed by
  * (seed, photon, draw), beams pushed in (photon, order) order.  The result

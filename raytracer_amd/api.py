@@ -202,6 +202,27 @@ def quantise_argb(rgb):
     return out
 
 
+def write_segments_file(path, segs, root_lo, root_hi):
+    """pb_write_segments_file: the segment set and its root box as a file (host code, no GPU)."""
+    segs = np.ascontiguousarray(segs)
+    if segs.dtype != SEGMENT_DTYPE:
+        raise ValueError("segments must have SEGMENT_DTYPE")
+    _check(library().pb_write_segments_file(os.fsencode(path), segs.ctypes.data_as(C.c_void_p), C.c_int(len(segs)),
+                                            _fp(_f32(root_lo, 3)), _fp(_f32(root_hi, 3))), "pb_write_segments_file")
+
+
+def read_segments_file(path):
+    """pb_read_segments_file: (segments, root_lo, root_hi) (host code, no GPU)."""
+    n = C.c_int(0)
+    lo = np.zeros(3, np.float32); hi = np.zeros(3, np.float32)
+    L = library()
+    _check(L.pb_read_segments_file(os.fsencode(path), None, C.c_int(0), C.byref(n), _fp(lo), _fp(hi)), "pb_read_segments_file")
+    segs = np.zeros(n.value, SEGMENT_DTYPE)
+    _check(L.pb_read_segments_file(os.fsencode(path), segs.ctypes.data_as(C.c_void_p), C.c_int(n.value), C.byref(n), _fp(lo), _fp(hi)),
+           "pb_read_segments_file")
+    return segs, lo, hi
+
+
 class Context:
     """One GPU's state for the path: scene, segment set, LBVH.  One per process and GPU."""
 
@@ -315,6 +336,12 @@ class Context:
     def upload_segments_device(self, d_ptr, n, root_lo, root_hi, stream=0):
         _check(self.L.pb_upload_segments_d(self.h, C.c_void_p(d_ptr), C.c_int(n), _fp(_f32(root_lo, 3)),
                                            _fp(_f32(root_hi, 3)), C.c_void_p(stream)), "pb_upload_segments_d")
+
+    def save_segments(self, path):
+        _check(self.L.pb_save_segments(self.h, os.fsencode(path)), "pb_save_segments")
+
+    def load_segments(self, path):
+        _check(self.L.pb_load_segments(self.h, os.fsencode(path)), "pb_load_segments")
 
     def segment_count(self):
         n = C.c_int(0)

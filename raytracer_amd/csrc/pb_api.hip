@@ -663,6 +663,28 @@ int pb_download_segments(pb_ctx* ctx, pb_segment* out, int capacity, int* n_out)
   return PB_OK;
 }
 
+int pb_save_segments(pb_ctx* ctx, const char* path) {
+  if (!ctx || !path) { pb_set_error("pb_save_segments: null argument"); return PB_ERR_ARG; }
+  if (!ctx->have_segments) { pb_set_error("pb_save_segments: no segment set"); return PB_ERR_STATE; }
+  std::vector<pb_segment> segs((size_t)ctx->n_seg);
+  int n = 0;
+  int rc = pb_download_segments(ctx, segs.data(), ctx->n_seg, &n);
+  if (rc != PB_OK) return rc;
+  return pb_write_segments_file(path, segs.data(), n, ctx->root_lo, ctx->root_hi);
+}
+
+int pb_load_segments(pb_ctx* ctx, const char* path) {
+  if (!ctx || !path) { pb_set_error("pb_load_segments: null argument"); return PB_ERR_ARG; }
+  int n = 0;
+  float lo[3], hi[3];
+  int rc = pb_read_segments_file(path, nullptr, 0, &n, lo, hi);
+  if (rc != PB_OK) return rc;
+  std::vector<pb_segment> segs((size_t)n);
+  rc = pb_read_segments_file(path, segs.data(), n, &n, lo, hi);
+  if (rc != PB_OK) return rc;
+  return pb_upload_segments(ctx, segs.data(), n, lo, hi);
+}
+
 int pb_get_root_box(pb_ctx* ctx, float root_lo[3], float root_hi[3]) {
   if (!ctx || !root_lo || !root_hi) { pb_set_error("pb_get_root_box: null argument"); return PB_ERR_ARG; }
   if (!ctx->have_segments) { pb_set_error("pb_get_root_box: no segment set"); return PB_ERR_STATE; }

@@ -341,6 +341,21 @@ void DrawHet(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, Node
   check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
 }
 
+void LoadSegments(const char* path, const mat4& matrix, const std::vector<Triangle>& triangles) {
+  extinction_c = absorption_c + scattering_c;
+  recreate_context_if_control_changed();
+  pb_ctx* ctx = context();
+  std::vector<float> tri(triangles.size() * 9);
+  for (size_t i = 0; i < triangles.size(); ++i) {
+    const vec4* v[3] = {&triangles[i].v0, &triangles[i].v1, &triangles[i].v2};
+    for (int k = 0; k < 3; ++k) { tri[i * 9 + k * 3] = v[k]->x; tri[i * 9 + k * 3 + 1] = v[k]->y; tri[i * 9 + k * 3 + 2] = v[k]->z; }
+  }
+  g_triangles = triangles;
+  check(pb_set_scene(ctx, tri.data(), (int)triangles.size(), &matrix.m[0][0]), "pb_set_scene");
+  check(pb_load_segments(ctx, path), "pb_load_segments");
+}
+void SaveSegments(const char* path) { check(pb_save_segments(context(), path), "pb_save_segments"); }
+
 pb_stats Stats() {
   pb_stats s;
   check(pb_counters(context(), &s), "pb_counters");

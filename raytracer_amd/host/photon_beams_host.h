@@ -106,6 +106,12 @@ void DrawHet(screen* screen, std::vector<PhotonBeam> beams_const, std::vector<Ph
 // (analysis_extinction = EXT_ANALYSIS = 0.04f widened, Control.h:21, Analysis.h:15).
 void RunAnalysis();
 
+// Not in the reference: the segment set as a file (pb_save_segments / pb_load_segments).  LoadSegments stands in for
+// CastPhotonBeams + BoundPhotonBeams + BuildTree when a set dumped elsewhere is to be drawn (it takes the matrix and
+// the triangles those calls would have been given); SaveSegments dumps what the next Draw* would use.
+void LoadSegments(const char* path, const mat4& matrix, const std::vector<Triangle>& triangles);
+void SaveSegments(const char* path);
+
 // Counters and device times of the last calls (pb_counters).
 pb_stats Stats();
 // Releases the GPU context (the reference leaks its tree; a long-running host may not want to).

@@ -211,3 +211,30 @@ def test_run_analysis_reproduces_reference_csv(golden_dir):
     assert nsd == open(os.path.join(golden_dir, "reference_NSD.csv")).read()
     assert rrmse == open(os.path.join(golden_dir, "ref_rRMSE.csv")).read()
     assert nsd.count("\n") == 250 and rrmse.count("\n") == 317
+
+
+def test_segment_file_fixture_is_the_config1_tree_set(cfg1, golden_dir, tmp_path):
+    """tests/golden/cfg1_tree_segments.bin (written by tests/golden/make_cfg1_segments.py) holds exactly the
+    oracle's configuration-1 tree segments and root box; the file functions of the C ABI (host code) round-trip
+    a set byte for byte and refuse what is not a segment file."""
+    import raytracer_amd as pb
+    o = cfg1[0]
+    segs, lo, hi = pb.read_segments_file(os.path.join(golden_dir, "cfg1_tree_segments.bin"))
+    want = o.export_segments(tree=True)
+    assert len(segs) == 987 and segs.tobytes() == want.tobytes()
+    wlo, whi = o.root_box()
+    assert np.array_equal(lo, wlo) and np.array_equal(hi, whi)
+    raw = open(os.path.join(golden_dir, "cfg1_tree_segments.bin"), "rb").read()
+    assert raw[:8] == b"PBSEGS\x00\x01" and len(raw) == 64 + 987 * 112
+    p = str(tmp_path / "copy.bin")
+    pb.write_segments_file(p, segs[:5], lo, hi)
+    s2, l2, h2 = pb.read_segments_file(p)
+    assert s2.tobytes() == segs[:5].tobytes() and np.array_equal(l2, lo) and np.array_equal(h2, hi)
+    pb.write_segments_file(p, segs[:0], lo, hi)
+    assert len(pb.read_segments_file(p)[0]) == 0
+    open(p, "wb").write(b"not a segment file" * 10)
+    with pytest.raises(pb.PhotonBeamsError):
+        pb.read_segments_file(p)
+    open(p, "wb").write(raw[:64 + 100])                       # truncated
+    with pytest.raises(pb.PhotonBeamsError):
+        pb.read_segments_file(p)
