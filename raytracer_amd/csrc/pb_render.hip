@@ -1217,6 +1217,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // its own waits, which only makes those waits stricter.  The survivors' indices sit in a VGPR (lane j: survivor j)
 // and are picked with v_readlane, so the loop touches LDS once per 64 candidates.  The tile's pyramid planes come
 // from row 7 of its ray block (ray_setup_body) instead of being normalised again by every item.
+// Tried and dropped: the survivors' records copied to LDS and read back as vector operands (a vector instruction
+// with a scalar-register source issues in 4.3 cycles against 2.6 on vector registers alone, tools/micro/valu_rate.hip):
+// 0.245 ms against 0.223 ms at 10 000 photons, 0.277 ms with the next record requested a candidate ahead (80 registers).
 struct SegHalfA { float Rinv[9]; float ox2, oz2, c4, oy, len, tb0; uint32_t qflags; };      // SegFrame dwords 0..15
 struct SegHalfB { double W[3]; float lo[3], hi[3], cand[3]; float Sinv; };                  // SegFrame dwords 16..31
 static_assert(sizeof(SegHalfA) == 64 && sizeof(SegHalfB) == 64, "halves of the first 128 bytes of SegFrame");
@@ -1296,6 +1299,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     ns += __builtin_popcountll(mask);
   }
   __syncthreads();
+  // A SIMD shares its issue slots among up to eight items, and the kernel ends with its longest one: items with many
+  // survivors go first in the SIMD's arbitration, the short ones fill the slots they leave.
+  if (ns > 32) __builtin_amdgcn_s_setprio(3);
+  else if (ns > 16) __builtin_amdgcn_s_setprio(2);
+  else if (ns > 8) __builtin_amdgcn_s_setprio(1);
   // 2. every lane evaluates its own ray against each survivor
   PairSums sum;
   sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = 0u;
