@@ -258,7 +258,7 @@ int pb_render_strips_d(pb_ctx* ctx, int first_strip, int strip_stride, int n_str
 #define PB_NOALLOC_MAX_GROUPS 4096          /* 8x8-pixel tiles x SSAA^2 of the rectangle: 512x512 at SSAA 1     */
 #define PB_NOALLOC_MAX_LIST_ENTRIES 1048576 /* (64x64-pixel macro tile, segment) incidences of the frame        */
 #define PB_NOALLOC_MAX_ITEMS 131072         /* evaluation items (tile x slice of its macro tile's list)         */
-#define PB_NOALLOC_SCRATCH_BYTES (26u << 20) /* the array: 26 MiB per GPU                                        */
+#define PB_NOALLOC_SCRATCH_BYTES (28u << 20) /* the array: 28 MiB per GPU                                        */
 int pb_render_noalloc_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, float* d_rgb_out, void* stream);
 
 /* Arithmetic of the per-pair estimate.  0 (default): fused multiply-adds, hardware reciprocal and

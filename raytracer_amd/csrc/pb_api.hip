@@ -55,7 +55,7 @@ constexpr size_t NOALLOC_BLK_WORDS = (size_t)1 << 18;                  // (binni
 constexpr size_t SCRATCH_BLK = SCRATCH_BIN_LIST + align256(sizeof(uint32_t) * (size_t)PB_NOALLOC_MAX_LIST_ENTRIES);
 constexpr size_t SCRATCH_ITEMS = SCRATCH_BLK + align256(sizeof(uint32_t) * NOALLOC_BLK_WORDS);
 constexpr size_t SCRATCH_ACCUM = SCRATCH_ITEMS + align256(sizeof(uint32_t) * 4 * (size_t)PB_NOALLOC_MAX_ITEMS);
-constexpr size_t SCRATCH_BYTES = SCRATCH_ACCUM + align256(sizeof(unsigned long long) * 3 * 64 * (size_t)PB_NOALLOC_MAX_GROUPS);
+constexpr size_t SCRATCH_BYTES = SCRATCH_ACCUM + align256(sizeof(unsigned long long) * PB_ACC_PLANES * 64 * (size_t)PB_NOALLOC_MAX_GROUPS);
 static_assert(SCRATCH_BYTES <= (size_t)PB_NOALLOC_SCRATCH_BYTES, "the layout must fit the stated size of the static workspace");
 
 static __device__ __align__(256) unsigned char scratch[PB_NOALLOC_SCRATCH_BYTES];
@@ -212,7 +212,7 @@ int ensure_bin_workspace(FrameWorkspace& ws, int tiles, int bin_cap, int item_ca
   if (accum_px > ws.ws_accum_px) {
     if (ws.d_accum) PB_HIP(hipFree(ws.d_accum));
     ws.d_accum = nullptr; ws.ws_accum_px = 0;
-    PB_HIP(hipMalloc(&ws.d_accum, sizeof(unsigned long long) * 3 * accum_px));
+    PB_HIP(hipMalloc(&ws.d_accum, sizeof(unsigned long long) * PB_ACC_PLANES * accum_px));
     ws.ws_accum_px = accum_px;
   }
   return PB_OK;
@@ -283,6 +283,9 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       // The list offsets and the item queue are functions of the segment set and the frame geometry alone and are in
       // the workspace from the frame that sized it for this key: ray set-up + the fill of the lists, evaluation, pixels.
       p.n_items_host = ws.ws_items_needed;
+      // runs of 64 queue items per XCD: a tile's items share an L2 (cfg2: 91 -> 60 MB fetched by the evaluation, same
+      // time; 512^2 / 1000 photons 0.0447 -> 0.0420 ms); frames with very many items lose 2 % to it and deal singly
+      if (p.xcd_run < 0) p.xcd_run = ws.ws_items_needed <= (1 << 17) ? 64 : 0;
       p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !std::getenv("PB_SEPARATE_FINALIZE")) ? 1 : 0;
       rc = pb_launch_fast_frame(p, mode, s);
       if (rc != PB_OK) return rc;
@@ -293,7 +296,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
       PB_HIP(hipMemsetAsync(ws.d_ctrl, 0, sizeof(uint32_t) * 4, s));
       PB_HIP(hipMemsetAsync(p.sub_count, 0, sizeof(uint32_t) * 2 * (size_t)ws.ws_tiles * PB_BIN_SUBS, s));   // sub_count, sub_fill
-      PB_HIP(hipMemsetAsync(ws.d_accum, 0, sizeof(unsigned long long) * 3 * px, s));
+      PB_HIP(hipMemsetAsync(ws.d_accum, 0, sizeof(unsigned long long) * PB_ACC_PLANES * px, s));
     }
     rc = pb_launch_ray_setup(p, ctx->count_on, s);
     if (rc != PB_OK) return rc;
@@ -344,6 +347,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
   }
   if (!verified) { pb_set_error("pb_render: bin workspace could not be sized"); return PB_ERR_CAPACITY; }
   p.n_items_host = ws.ws_items_needed;
+  if (p.xcd_run < 0) p.xcd_run = 0;
   int rc = pb_launch_bin_fill_eval(p, mode, ctx->count_on, s);
   if (rc != PB_OK) return rc;
   ws.queue_kept = p.fused_queue != 0 && p.n_seg > 0;
@@ -403,6 +407,8 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   // a rank's share of interleaved strips has few items: shorter ones keep the longest wave short
   p.slice = ctx->tune_slice > 0 ? ctx->tune_slice : (strip_stride > 1 ? 96 : 128);   // render_binned refines it per frame geometry
   p.slice_whole = 0;
+  p.xcd_run = -1;           // chosen with the item count in render_binned
+  if (const char* e = std::getenv("PB_TUNE_XCDRUN")) { int v = std::atoi(e); if (v >= 0 && v <= 4096) p.xcd_run = v; }
   if (const char* e = std::getenv("PB_TUNE_WHOLE")) { int v = std::atoi(e); if (v >= 0 && v <= PB_SLICE) p.slice_whole = v; }
   p.eval_waves = ctx->tune_waves;
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;

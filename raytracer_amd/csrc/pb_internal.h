@@ -149,8 +149,9 @@ struct RenderParams {
   uint32_t* macro_rank;     // [macro tiles] position in the evaluation queue, longest list first
   uint32_t* tile_items;     // [tiles] evaluation items of the tile (written with the items, kept with them)
   uint32_t* tile_done;      // [tiles] items of the tile that have added their sums this frame (finalize_in_eval)
+  int xcd_run;              // evaluation items per run that one XCD takes (0: items are dealt singly round the XCDs)
   int finalize_in_eval;     // 1: the last item of a tile writes its pixels; tiles without items are written by ray set-up
-  unsigned long long* accum;// [out_h*out_w][3] fixed-point radiance sums
+  unsigned long long* accum;// [tiles][PB_ACC_PLANES][64] fixed-point radiance sums; a pixel's channel = its plane + the common plane
   int bin_capacity, item_capacity;
   int macro_w;              // tile columns per macro tile
   int macro_h;              // tile rows per macro tile (fewer when the rows are interleaved strips)
@@ -168,6 +169,7 @@ struct RenderParams {
 };
 
 constexpr int PB_RAY_WORDS = 12;       // floats stored per camera ray
+constexpr int PB_ACC_PLANES = 4;       // pixel sums per tile: red, green, blue, and what is common to all three
 constexpr int PB_CHUNK = 124;          // candidates per chunk
 constexpr int PB_CHUNK_WORDS = 128;    // 4 header words + PB_CHUNK indices = 512 B
 constexpr int PB_EVAL_WAVES = 256 * 32;

@@ -501,8 +501,8 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
     // this launch also clears the pixel sums the frame accumulates into (the bin counters are cleared by
     // the previous frame's finalize_kernel)
     if (sub == 0) {
-      unsigned long long* a = p.accum + (size_t)tile * 3 * 64 + lane;   // [tile][channel][lane]
-      a[0] = 0ull; a[64] = 0ull; a[128] = 0ull;
+      unsigned long long* a = p.accum + (size_t)tile * PB_ACC_PLANES * 64 + lane;   // [tile][plane][lane]
+      a[0] = 0ull; a[64] = 0ull; a[128] = 0ull; a[192] = 0ull;
       if (p.finalize_in_eval) {
         if (lane == 0) p.tile_done[tile] = 0u;
         // no evaluation item will come by this tile: its pixels are written here
@@ -1173,7 +1173,7 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
     if (nc) {
       // sums are kept per tile, [tile][channel][lane]: one atomic instruction covers 512 contiguous bytes
       // (the adds run at the memory side in 64-byte requests; pixel-major rows cost three times as many)
-      unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
+      unsigned long long* dst = p.accum + (size_t)tile * PB_ACC_PLANES * 64 + lane;
       const unsigned long long bias = (unsigned long long)nc * magic_bits;
       atomicAdd(&dst[0], ai[0] + ag - bias);
       atomicAdd(&dst[64], ai[1] + ag - bias);
@@ -1230,7 +1230,7 @@ PB_DI void smem_load16(u32x16& dst, const SegFrame* base, uint32_t byte_offset) 
 PB_DI void smem_wait(u32x16& a, u32x16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
 PB_DI void smem_wait(u32x16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
 
-struct PairSums { unsigned long long ai[3]; unsigned long long ag; uint32_t nc; };
+struct PairSums { unsigned long long ai[3]; unsigned long long ag; uint32_t nc, ng; };   // nc / ng: terms in ai / in ag
 
 // One candidate: `cur` holds the first half of its record (loaded and waited for); requests the second half and the
 // first half of the next candidate's record into `nxt`, evaluates, waits, accumulates.
@@ -1252,12 +1252,13 @@ PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t 
     const double integral = (double)value;               // carries the 2^-10 of the fixed-point sums
     if (a.qflags & 64u) {
       sum.ag += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
+      sum.ng++;
     } else {
       sum.ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
       sum.ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[1], integral, PB_FIX_MAGIC));
       sum.ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[2], integral, PB_FIX_MAGIC));
+      sum.nc++;
     }
-    sum.nc++;
   }
 }
 
@@ -1267,7 +1268,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const int lane = threadIdx.x;
   const uint32_t produced = p.ctrl[0];
   const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
-  const uint32_t c = blockIdx.x;
+  // Workgroups go round the eight XCDs by their index, and each XCD has an L2 of its own: the items of one tile, which
+  // are neighbours in the queue and read the same rays and much the same records, are kept on one XCD by handing out
+  // the queue in runs of xcd_run items (the runs still go round the XCDs, longest lists first).
+  uint32_t c = blockIdx.x;
+  if (p.xcd_run > 0) {
+    const uint32_t run_len = (uint32_t)p.xcd_run, xcd = c & 7u, j = c >> 3;
+    c = ((j / run_len) * 8u + xcd) * run_len + j % run_len;
+  }
   if (c >= n_items) return;
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
   const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
@@ -1306,7 +1314,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   else if (ns > 8) __builtin_amdgcn_s_setprio(1);
   // 2. every lane evaluates its own ray against each survivor
   PairSums sum;
-  sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = 0u;
+  sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = sum.ng = 0u;
   const SegFrame* frames = p.frames;
   const float extinction = p.extinction_c;
   for (int b0 = 0; b0 < ns; b0 += 64) {
@@ -1327,13 +1335,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     if (k < nb) pair_step(frames, ra, rb, off_cur, off_cur, r, extinction, sum);
   }
-  unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
+  unsigned long long* dst = p.accum + (size_t)tile * PB_ACC_PLANES * 64 + lane;
+  // A segment whose beam has met no coloured wall weighs the three channels alike (most do): its terms go to the
+  // tile's fourth plane, one atomic instruction instead of three; the pixel write-out adds that plane to each channel.
+  const unsigned long long grey = sum.ag - (unsigned long long)sum.ng * magic_bits;
+  const unsigned long long bias = (unsigned long long)sum.nc * magic_bits;
   if (!FINALIZE) {
+    if (sum.ng) atomicAdd(&dst[192], grey);
     if (sum.nc) {
-      const unsigned long long bias = (unsigned long long)sum.nc * magic_bits;
-      atomicAdd(&dst[0], sum.ai[0] + sum.ag - bias);
-      atomicAdd(&dst[64], sum.ai[1] + sum.ag - bias);
-      atomicAdd(&dst[128], sum.ai[2] + sum.ag - bias);
+      atomicAdd(&dst[0], sum.ai[0] - bias);
+      atomicAdd(&dst[64], sum.ai[1] - bias);
+      atomicAdd(&dst[128], sum.ai[2] - bias);
     }
   } else {
     // The item that finds all the others of its tile done writes the tile's pixels.  Everything is exchanged through
@@ -1341,20 +1353,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // written back or invalidated (an agent-scope release per item made this kernel fifteen times slower): the
     // additions return their old values, the wave waits for them - the sums are then in place - and only then counts
     // itself done; the wave that reads the full count fetches the sums by adding zero.
-    unsigned long long r0 = 0ull, r1 = 0ull, r2 = 0ull;
-    if (sum.nc) {
-      const unsigned long long bias = (unsigned long long)sum.nc * magic_bits;
-      r0 = atomicAdd(&dst[0], sum.ai[0] + sum.ag - bias);
-      r1 = atomicAdd(&dst[64], sum.ai[1] + sum.ag - bias);
-      r2 = atomicAdd(&dst[128], sum.ai[2] + sum.ag - bias);
+    const uint32_t items_of_tile = pb_uniform(p.tile_items)[tile];
+    if (items_of_tile == 1u) {
+      // the tile's only item: its sums are the pixels, nothing to exchange
+      const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
+      const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
+      if (ox < p.out_w && oy < p.out_h) {
+        const double inv = PB_FIX_SCALE / (double)p.ssaa;      // skeleton.cpp:361: current / (double) SSAA
+        float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
+        o[0] = (float)((double)(long long)(sum.ai[0] - bias + grey) * inv);
+        o[1] = (float)((double)(long long)(sum.ai[1] - bias + grey) * inv);
+        o[2] = (float)((double)(long long)(sum.ai[2] - bias + grey) * inv);
+      }
+      return;
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
+    unsigned long long r0 = 0ull, r1 = 0ull, r2 = 0ull, r3 = 0ull;
+    if (sum.ng) r3 = atomicAdd(&dst[192], grey);
+    if (sum.nc) {
+      r0 = atomicAdd(&dst[0], sum.ai[0] - bias);
+      r1 = atomicAdd(&dst[64], sum.ai[1] - bias);
+      r2 = atomicAdd(&dst[128], sum.ai[2] - bias);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
     uint32_t before = 0u;
     if (lane == 0) before = __hip_atomic_fetch_add(&p.tile_done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-    if (before + 1u == pb_uniform(p.tile_items)[tile]) {
+    if (before + 1u == items_of_tile) {
       asm volatile("" : : : "memory");
-      const unsigned long long v0 = atomicAdd(&dst[0], 0ull), v1 = atomicAdd(&dst[64], 0ull), v2 = atomicAdd(&dst[128], 0ull);
+      const unsigned long long vg = atomicAdd(&dst[192], 0ull);
+      const unsigned long long v0 = atomicAdd(&dst[0], 0ull) + vg, v1 = atomicAdd(&dst[64], 0ull) + vg, v2 = atomicAdd(&dst[128], 0ull) + vg;
       const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
       const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
       if (ox < p.out_w && oy < p.out_h) {
@@ -1497,7 +1524,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __syncthreads();
     const unsigned long long a0 = s_acc[0][lane], a1 = s_acc[1][lane], a2 = s_acc[2][lane];
     if (a0 | a1 | a2) {
-      unsigned long long* dst = p.accum + (size_t)tile * 3 * 64 + lane;
+      unsigned long long* dst = p.accum + (size_t)tile * PB_ACC_PLANES * 64 + lane;
       atomicAdd(&dst[0], a0);
       atomicAdd(&dst[64], a1);
       atomicAdd(&dst[128], a2);
@@ -1521,9 +1548,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
   const double inv = PB_FIX_SCALE / (double)p.ssaa;      // skeleton.cpp:361: current / (double) SSAA
   const int ox = (int)(i % (size_t)p.out_w), oy = (int)(i / (size_t)p.out_w);
   const size_t tile = (size_t)(oy >> 3) * p.tiles_x + (ox >> 3);
-  const unsigned long long* a = p.accum + tile * 3 * 64 + ((oy & 7) * 8 + (ox & 7));
+  const unsigned long long* a = p.accum + tile * PB_ACC_PLANES * 64 + ((oy & 7) * 8 + (ox & 7));
   for (int k = 0; k < 3; ++k) {
-    const long long v = (long long)a[k * 64];
+    const long long v = (long long)(a[k * 64] + a[3 * 64]);
     p.out[i * 3 + k] = (float)((double)v * inv);
   }
 }
@@ -1647,6 +1674,7 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
   else if (count) hipLaunchKernelGGL((eval_bins_kernel<true, false, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (p.precise) hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (pb_pipelined_eval(p, mode)) {
+    if (p.xcd_run > 0) waves = (waves + 8 * p.xcd_run - 1) / (8 * p.xcd_run) * (8 * p.xcd_run);    // whole runs for every XCD
     if (p.finalize_in_eval) {
       hipLaunchKernelGGL(eval_items_fast_kernel<true>, dim3(waves), dim3(64), 0, s, p);
       PB_HIP(hipGetLastError());

@@ -10,7 +10,7 @@ Passes (each one rocprofv3 run of its own; counters never share a run with --ker
           SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_SCA, SQ_WAVES
   fetch   FETCH_SIZE          write   WRITE_SIZE
 The counter passes end in <out_dir>/<W>_pmc.json: per kernel of the timed frames the mean per launch of
-every counter, the hardware-counted FP32 operations per frame (64 lanes x (ADD + MUL + 2 FMA + TRANS)
+every counter (only kernels launched once per timed step count as the frame's), the hardware-counted FP32 operations per frame (64 lanes x (ADD + MUL + 2 FMA + TRANS)
 wave-level instructions) and the HBM bytes per frame (FETCH_SIZE doubled: gfx950 tallies 128-byte
 requests at 64 bytes; both counters are in KiB), stamped with the hash of the kernel sources they were
 measured on (bench.py compares it with the sources it runs).
@@ -87,7 +87,7 @@ def counters(d):
             k = short(name)
             tot[k][cname] += float(val)
             calls[k].add(disp)
-    return {k: {c: v / len(calls[k]) for c, v in tot[k].items()} for k in tot}
+    return {k: dict({c: v / len(calls[k]) for c, v in tot[k].items()}, launches=len(calls[k])) for k in tot}
 
 
 def main():
@@ -109,7 +109,9 @@ def main():
         print(f"[profile_frame] {workload} {name} done", flush=True)
     if not per_kernel:
         return
-    frame = {k: v for k, v in per_kernel.items() if is_frame_kernel(k)}
+    # a kernel of the timed frames is launched once per step (20 + 3 warm-up); what the sizing frame and the counted
+    # frame launch once or twice is left out
+    frame = {k: v for k, v in per_kernel.items() if is_frame_kernel(k) and v.get("launches", 0) >= 20}
     flops = sum(64.0 * (v.get("SQ_INSTS_VALU_ADD_F32", 0) + v.get("SQ_INSTS_VALU_MUL_F32", 0) +
                         2 * v.get("SQ_INSTS_VALU_FMA_F32", 0) + v.get("SQ_INSTS_VALU_TRANS_F32", 0)) for v in frame.values())
     fetch = sum(2 * 1024.0 * v.get("FETCH_SIZE", 0) for v in frame.values())
