@@ -392,6 +392,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   p.het = ctx->d_het; p.het_axis = ctx->d_het_axis; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side; p.grid_fast_div = ctx->grid_fast_div;
   p.one_dimensional = ctx->ctl.one_dimensional;
   p.short_view = ctx->ctl.short_view; p.view_seed = ctx->ctl.seed;
+  p.store_d1 = mode != PB_MODE_721 ? 1 : 0;
   if (generic_het && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_GENERIC with one_dimensional and heterogeneous set needs pb_set_grid"); return PB_ERR_STATE; }
   if (mode == PB_MODE_73HET && !ctx->d_grid) { pb_set_error("pb_render: PB_MODE_73HET needs pb_set_grid"); return PB_ERR_STATE; }
   p.x0 = x0; p.y0 = y0; p.out_w = out_w; p.out_h = out_h; p.strip_stride = strip_stride;

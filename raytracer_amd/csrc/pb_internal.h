@@ -150,6 +150,7 @@ struct RenderParams {
   uint32_t* tile_items;     // [tiles] evaluation items of the tile (written with the items, kept with them)
   uint32_t* tile_done;      // [tiles] items of the tile that have added their sums this frame (finalize_in_eval)
   int xcd_run;              // evaluation items per run that one XCD takes (0: items are dealt singly round the XCDs)
+  int store_d1;             // ray set-up also stores the once-normalised direction (estimators other than Integral_721)
   int finalize_in_eval;     // 1: the last item of a tile writes its pixels; tiles without items are written by ray set-up
   unsigned long long* accum;// [tiles][PB_ACC_PLANES][64] fixed-point radiance sums; a pixel's channel = its plane + the common plane
   int bin_capacity, item_capacity;

@@ -140,6 +140,18 @@ PB_DI void tile_planes(const RenderParams& p, int tx, int tk, V3 pl[4]) {
   pl[2] = normalize3(v3(0.0f, p.focal, -yt));
   pl[3] = normalize3(v3(0.0f, -p.focal, yb));
 }
+// Plane k of tile_planes alone, bit for bit (k may differ from lane to lane).
+PB_DI V3 tile_plane(const RenderParams& p, int tx, int tk, int k) {
+  const float half_w = (p.width * p.ssaa) / (float)2, half_h = (p.height * p.ssaa) / (float)2;
+  const float xl = (float)((p.x0 + 8 * tx) * p.ssaa) - half_w - 0.5f;
+  const float xr = (float)((p.x0 + 8 * tx + 7) * p.ssaa + p.ssaa - 1) - half_w + 0.5f;
+  const int ty0 = p.y0 + 8 * tk * p.strip_stride;
+  const float yt = (float)(ty0 * p.ssaa) - half_h - 0.5f;
+  const float yb = (float)((ty0 + 7) * p.ssaa + p.ssaa - 1) - half_h + 0.5f;
+  const float f = (k & 1) ? -p.focal : p.focal;
+  const float off = k == 0 ? -xl : (k == 1 ? xr : (k == 2 ? -yt : yb));
+  return normalize3(k < 2 ? v3(f, 0.0f, off) : v3(0.0f, f, off));
+}
 
 template <bool COUNT>
 __global__ __launch_bounds__(64) void cull_scan_kernel(const RenderParams p) {
@@ -502,14 +514,19 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
     // the previous frame's finalize_kernel)
     if (sub == 0) {
       unsigned long long* a = p.accum + (size_t)tile * PB_ACC_PLANES * 64 + lane;   // [tile][plane][lane]
-      a[0] = 0ull; a[64] = 0ull; a[128] = 0ull; a[192] = 0ull;
       if (p.finalize_in_eval) {
-        if (lane == 0) p.tile_done[tile] = 0u;
-        // no evaluation item will come by this tile: its pixels are written here
-        if (pb_uniform(p.tile_items)[tile] == 0u && ox < p.out_w && oy < p.out_h) {
+        // no evaluation item will come by this tile: its pixels are written here; a single item writes them itself
+        // and needs no sums
+        const uint32_t items_of_tile = pb_uniform(p.tile_items)[tile];
+        if (items_of_tile > 1u) {
+          a[0] = 0ull; a[64] = 0ull; a[128] = 0ull; a[192] = 0ull;
+          if (lane == 0) p.tile_done[tile] = 0u;
+        } else if (items_of_tile == 0u && ox < p.out_w && oy < p.out_h) {
           float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
           o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
         }
+      } else {
+        a[0] = 0ull; a[64] = 0ull; a[128] = 0ull; a[192] = 0ull;
       }
     }
   }
@@ -551,14 +568,16 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
   // row 7, lanes 0..11: the four side planes of the tile's pyramid, which every evaluation item of the tile needs
   float plane_word = 0.0f;
   {
-    V3 pl[4];
-    tile_planes(p, tx, tk, pl);
-    const float w[12] = {pl[0].x, pl[0].y, pl[0].z, pl[1].x, pl[1].y, pl[1].z, pl[2].x, pl[2].y, pl[2].z, pl[3].x, pl[3].y, pl[3].z};
-#pragma unroll
-    for (int j = 0; j < 12; ++j) plane_word = (lane == j) ? w[j] : plane_word;
+    // lane j computes component j % 3 of plane j / 3 with tile_planes' own arithmetic (one normalisation per lane
+    // instead of four by all of them)
+    const int k = (lane < 12) ? lane / 3 : 0, comp = lane - 3 * (lane / 3);
+    const V3 n = tile_plane(p, tx, tk, k);
+    plane_word = (lane < 12) ? (comp == 0 ? n.x : (comp == 1 ? n.y : n.z)) : 0.0f;
   }
   rr[6 * 64 + lane] = r.maxd; rr[7 * 64 + lane] = plane_word;
-  rr[8 * 64 + lane] = r.d1.x; rr[9 * 64 + lane] = r.d1.y; rr[10 * 64 + lane] = r.d1.z; rr[11 * 64 + lane] = 0.0f;
+  if (p.store_d1) {    // the once-normalised direction: Integral_73 / Integral_73Het and the cones' Integral_721_ada
+    rr[8 * 64 + lane] = r.d1.x; rr[9 * 64 + lane] = r.d1.y; rr[10 * 64 + lane] = r.d1.z;
+  }
   const bool any = __ballot(r.active) != 0ull;
   if (lane == 0) p.group_last[group] = any ? 0 : -1;
   if (COUNT) {
