@@ -75,7 +75,8 @@ typedef struct pb_segment {
   int32_t seg_id;       /* PhotonSeg.seg_id                                      */
   int32_t id;           /* PhotonSeg.id (beam index)                             */
   uint32_t flags;       /* bit0 ada_width, bit1 scattered                        */
-  uint32_t reserved[3];
+  uint32_t reserved[3]; /* [0]: 1 on segments pb_emit_beams / pb_recast_beams made from the
+                           scattered list, else 0 (the renderer ignores it); [1..2] zero   */
 } pb_segment;
 
 /* One photon beam: PhotonBeam (CastPhotons.h:14-27) without the unused fields. */

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void bound_kernel(const BoundParams p) {
       s.s_ext = het ? e_prev : 0.f; s.e_ext = het ? e_cur : 0.f; s.c_ext = mean;
       s.seg_id = current_step; s.id = i;
       s.flags = ada ? 1u : 0u;
-      s.reserved[0] = s.reserved[1] = s.reserved[2] = 0u;
+      s.reserved[0] = (g >= p.n_const) ? 1u : 0u;   // which list the beam is in; PhotonSeg.scattered itself stays false
+      s.reserved[1] = s.reserved[2] = 0u;
       p.segs[base + count] = s;
     }
     count++;

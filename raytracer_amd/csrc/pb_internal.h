@@ -47,7 +47,7 @@ struct __attribute__((aligned(64))) SegFrame {
   float lo[3];     // 22..24  gate box, min_b of HitBoundingBox
   float hi[3];     // 25..27  max_b
   float cand[3];   // 28..30  candidate planes of HitBoundingBox for the origin (0,0,0)
-  float Sinv;      // 31      1/|end-start|
+  float vcap10;    // 31      most a crossing's integral may be, times 2^-10: PB_FIX_LIMIT / max(W) scaled likewise
   float R[9];      // 32..40  inverse(R_inv) (Intersections.h:443-444)
   float ox, oz;    // 41,42   T_inv.x, T_inv.z
   float bdir[3];   // 43..45  normalize(end-start)

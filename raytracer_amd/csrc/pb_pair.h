@@ -171,17 +171,18 @@ PB_DI int hit_cylinder_exact(const SegFrame& f, const Ray& r, CylHit& h) {
   const float sx = have_second ? ox + dpx * ths : 0.0f;
   const float sy = have_second ? oy + dpy * ths : 0.0f;
   const float sz = have_second ? oz + dpz * ths : 0.0f;
-  const float tb_a = f.tb0 + (fy / f.Sinv);
-  const float tb_b = f.tb0 + (sy / f.Sinv);
+  const float Sinv = 1 / f.len;   // S_inv of Intersections.h:321: the division made when the record was built, again
+  const float tb_a = f.tb0 + (fy / Sinv);
+  const float tb_b = f.tb0 + (sy / Sinv);
   const float tb_minus = fminf(tb_a, tb_b);
   const float ux = fx - ox, uy = fy - oy, uz = fz - oz;
-  const float ex = (f.R[0] * ux + f.R[3] * uy + f.R[6] * uz) / f.Sinv;
-  const float ey = (f.R[1] * ux + f.R[4] * uy + f.R[7] * uz) / f.Sinv;
-  const float ez = (f.R[2] * ux + f.R[5] * uy + f.R[8] * uz) / f.Sinv;
+  const float ex = (f.R[0] * ux + f.R[3] * uy + f.R[6] * uz) / Sinv;
+  const float ey = (f.R[1] * ux + f.R[4] * uy + f.R[7] * uz) / Sinv;
+  const float ez = (f.R[2] * ux + f.R[5] * uy + f.R[8] * uz) / Sinv;
   const float wx = sx - ox, wy = sy - oy, wz = sz - oz;
-  const float qx = (f.R[0] * wx + f.R[3] * wy + f.R[6] * wz) / f.Sinv;
-  const float qy = (f.R[1] * wx + f.R[4] * wy + f.R[7] * wz) / f.Sinv;
-  const float qz = (f.R[2] * wx + f.R[5] * wy + f.R[8] * wz) / f.Sinv;
+  const float qx = (f.R[0] * wx + f.R[3] * wy + f.R[6] * wz) / Sinv;
+  const float qy = (f.R[1] * wx + f.R[4] * wy + f.R[7] * wz) / Sinv;
+  const float qz = (f.R[2] * wx + f.R[5] * wy + f.R[8] * wz) / Sinv;
   h.entry = v3(ex, ey, ez);
   h.exit = v3(qx, qy, qz);
   h.tb_minus = tb_minus;
@@ -346,18 +347,19 @@ PB_DI int hit_cone_exact(const SegFrame& f, const ConeFrame& cf, const Ray& r, C
   const float sx = have_second ? ox + dpx * ths : 0.0f;
   const float sy = have_second ? oy + dpy * ths : 0.0f;
   const float sz = have_second ? oz + dpz * ths : 0.0f;
+  const float Sinv = 1 / f.len;   // S_inv of Intersections.h:158, as above
   const float ux = fx - ox, uy = fy - oy, uz = fz - oz;
-  const float ex = (f.R[0] * ux + f.R[3] * uy + f.R[6] * uz) / f.Sinv;
-  const float ey = (f.R[1] * ux + f.R[4] * uy + f.R[7] * uz) / f.Sinv;
-  const float ez = (f.R[2] * ux + f.R[5] * uy + f.R[8] * uz) / f.Sinv;
+  const float ex = (f.R[0] * ux + f.R[3] * uy + f.R[6] * uz) / Sinv;
+  const float ey = (f.R[1] * ux + f.R[4] * uy + f.R[7] * uz) / Sinv;
+  const float ez = (f.R[2] * ux + f.R[5] * uy + f.R[8] * uz) / Sinv;
   const float wx = sx - ox, wy = sy - oy, wz = sz - oz;
-  const float qx = (f.R[0] * wx + f.R[3] * wy + f.R[6] * wz) / f.Sinv;
-  const float qy = (f.R[1] * wx + f.R[4] * wy + f.R[7] * wz) / f.Sinv;
-  const float qz = (f.R[2] * wx + f.R[5] * wy + f.R[8] * wz) / f.Sinv;
+  const float qx = (f.R[0] * wx + f.R[3] * wy + f.R[6] * wz) / Sinv;
+  const float qy = (f.R[1] * wx + f.R[4] * wy + f.R[7] * wz) / Sinv;
+  const float qz = (f.R[2] * wx + f.R[5] * wy + f.R[8] * wz) / Sinv;
   h.entry = v3(ex, ey, ez);
   h.exit = v3(qx, qy, qz);
-  h.tb_minus = f.tb0 + (fy / f.Sinv);                               // :297-298: no ordering of the two
-  h.tb_plus = f.tb0 + (sy / f.Sinv);
+  h.tb_minus = f.tb0 + (fy / Sinv);                               // :297-298: no ordering of the two
+  h.tb_plus = f.tb0 + (sy / Sinv);
   h.tc_minus = pb_sqrt(ex * ex + ey * ey + ez * ez);
   h.tc_plus = pb_sqrt(qx * qx + qy * qy + qz * qz);
   return 2;

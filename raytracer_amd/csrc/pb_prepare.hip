@@ -155,7 +155,6 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
     for (int row = 0; row < 3; ++row) { f.Rinv[col * 3 + row] = Rinv.m[col][row]; f.R[col * 3 + row] = R.m[col][row]; }
   f.ox = Tinv.x; f.oy = Tinv.y; f.oz = Tinv.z;
   f.c4 = 4 * c;
-  f.Sinv = Sinv;
   // |seg.start - seg.orig_start| as a vec4 length, w = 1 - 1 = 0  (Intersections.h:440)
   V4 d4 = v4(start.x - ostart.x, start.y - ostart.y, start.z - ostart.z, 0.0f);
   f.tb0 = length4(d4);
@@ -188,7 +187,14 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
       double rad = (double)scattering_c / (PB_PI_REF * ((double)s.radius * (double)s.radius));
       w = w * rad;
     }
-    f.W[k] = w;
+    // the fixed-point sums take finite, non-negative terms: a zero radius or a negative or non-finite energy
+    // (uploaded records) weighs nothing or saturates instead of corrupting its tile's sums
+    if (!(w >= 0.0)) w = 0.0;
+    f.W[k] = fmin(w, 1e30);
+  }
+  {
+    const double wmax = fmax(f.W[0], fmax(f.W[1], f.W[2]));
+    f.vcap10 = (float)fmin(PB_FIX_LIMIT * PB_FIX_PRESCALE / wmax, 3.0e38);   // wmax = 0: no cap needed, none overflows
   }
   if (f.W[0] == f.W[1] && f.W[1] == f.W[2]) f.qflags |= 64u;
   f.radius = s.radius;

@@ -1172,6 +1172,10 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
             // 1/sin(theta) is unbounded for a beam seen end-on, 1/r^2 at a cone's apex: saturate far above
             // the display range
             integral = fmin(integral, PB_FIX_LIMIT / fmax(f.W[0], fmax(f.W[1], f.W[2])));
+          } else {
+            // a thin beam's weight grows as 1/r^2: saturate likewise; a NaN integral (degenerate record) adds nothing
+            const double cap = (double)f.vcap10 * (FOLDED ? 1.0 : 1024.0);
+            integral = (integral >= 0.0) ? fmin(integral, cap) : 0.0;
           }
           if (!FOLDED) integral = integral * PB_FIX_PRESCALE;
           if (f.qflags & 64u) {
@@ -1240,7 +1244,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // with a scalar-register source issues in 4.3 cycles against 2.6 on vector registers alone, tools/micro/valu_rate.hip):
 // 0.245 ms against 0.223 ms at 10 000 photons, 0.277 ms with the next record requested a candidate ahead (80 registers).
 struct SegHalfA { float Rinv[9]; float ox2, oz2, c4, oy, len, tb0; uint32_t qflags; };      // SegFrame dwords 0..15
-struct SegHalfB { double W[3]; float lo[3], hi[3], cand[3]; float Sinv; };                  // SegFrame dwords 16..31
+struct SegHalfB { double W[3]; float lo[3], hi[3], cand[3]; float vcap10; };                  // SegFrame dwords 16..31
 static_assert(sizeof(SegHalfA) == 64 && sizeof(SegHalfB) == 64, "halves of the first 128 bytes of SegFrame");
 
 PB_DI void smem_load16(u32x16& dst, const SegFrame* base, uint32_t byte_offset) {
@@ -1268,7 +1272,9 @@ PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t 
   bool ok = res == 2;
   if (ok && !pair_721_fast_sure(a.qflags, tc_minus, r.maxd)) ok = pair_721_fast_gate(b.lo, b.hi, b.cand, a.qflags, r);
   if (ok) {
-    const double integral = (double)value;               // carries the 2^-10 of the fixed-point sums
+    // carries the 2^-10 of the fixed-point sums; the median saturates a thin beam's 1/r^2 weight far above the
+    // display range and turns a NaN (degenerate record) into no contribution
+    const double integral = (double)__builtin_amdgcn_fmed3f(value, 0.0f, b.vcap10);
     if (a.qflags & 64u) {
       sum.ag += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
       sum.ng++;

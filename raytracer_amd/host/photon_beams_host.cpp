@@ -175,10 +175,11 @@ AABB RecastPhotonBeams(std::vector<PhotonBeam>&, std::vector<PhotonBeam>& beams_
 }
 
 void BoundPhotonBeams(std::vector<PhotonBeam>& beams, std::vector<PhotonSeg>& items, const std::vector<Triangle>&) {
-  // segments of the const list come first; PhotonSeg.id restarts at 0 for the scattered list (CastPhotons.h:227)
+  // segments of the const list come first (CastPhotons.h:227 numbers each list from 0, so ids cannot tell the
+  // lists apart); the library marks the scattered list's segments in reserved[0]
   size_t split = g_segs.size();
-  for (size_t i = 1; i < g_segs.size(); ++i)
-    if (g_segs[i].id < g_segs[i - 1].id) { split = i; break; }
+  for (size_t i = 0; i < g_segs.size(); ++i)
+    if (g_segs[i].reserved[0] != 0u) { split = i; break; }
   const bool first = (g_bound_calls++ == 0) && ((int)beams.size() == g_n_const);
   const size_t a = first ? 0 : split, b = first ? split : g_segs.size();
   for (size_t i = a; i < b; ++i) {

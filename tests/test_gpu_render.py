@@ -204,6 +204,41 @@ def test_degenerate_segments_are_harmless(pb):
     assert both.mean() > 0.99 and (err <= 2e-5 * np.maximum(1.0, np.abs(ref[both]))).all(), err.max()
 
 
+def test_overweight_and_nan_weight_segments_saturate_instead_of_corrupting_tiles(pb):
+    """The binned path sums contributions as fixed-point integers, valid below 4096 each.  An uploaded beam whose
+    weight energy / r^2 is far beyond that must saturate near PB_FIX_LIMIT = 2047 on the pixels it covers and
+    leave every other pixel of its tiles alone; a NaN energy weighs nothing.  (The reference would show an
+    over-bright or NaN pixel there: both are outside the display range.)"""
+    kw = dict(photon_number=300, bounces=1, screen_width=64, screen_height=64)
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        good = ctx.download_segments()
+        lo, hi = ctx.root_box()
+        ctx.build_tree()
+        clean = ctx.draw(cull="bins").astype(np.float64)
+        bad = np.zeros(2, pb.SEGMENT_DTYPE)
+        bad["radius"] = 0.02; bad["seg_id"] = 1
+        bad["cull_lo"] = [-1, -1, 2]; bad["cull_hi"] = [1, 1, 4]
+        bad["start"] = [-0.4, -0.3, 2.6]; bad["end"] = [0.3, 0.2, 2.9]; bad["orig_start"] = bad["start"]
+        bad["energy"][0] = [1e12, 1e12, 2e12]
+        bad["start"][1] = [-0.4, 0.3, 2.6]; bad["end"][1] = [0.3, -0.2, 2.9]; bad["orig_start"][1] = bad["start"][1]
+        bad["energy"][1] = [np.nan, np.nan, np.nan]
+        ctx.upload_segments(np.concatenate([good, bad[1:]]), lo, hi)
+        ctx.build_tree()
+        nan_weight = ctx.draw(cull="bins").astype(np.float64)
+        ctx.upload_segments(np.concatenate([good[:50], bad, good[50:]]), lo, hi)
+        ctx.build_tree()
+        bins = ctx.draw(cull="bins").astype(np.float64)
+        scan = ctx.draw(cull="scan").astype(np.float64)     # floating-point sums: no saturation
+    np.testing.assert_array_equal(nan_weight, clean)
+    assert np.isfinite(bins).all()
+    over = scan.max(axis=2) > 2000.0
+    assert 10 < over.sum() < 0.2 * over.size
+    assert (bins[over].max(axis=1) >= 2000.0).all() and (bins[over] < 3 * 2048.0).all()
+    np.testing.assert_allclose(bins[~over], scan[~over], rtol=1e-5, atol=1e-7)
+
+
 def test_large_frame_takes_the_multi_kernel_queue_path(pb):
     """Frames above 16384 tiles build the evaluation queue with the multi-kernel path (device-wide
     scans) instead of the single-block one: 1160 x 1096 pixels = 145 x 137 tiles.  All three candidate
