@@ -252,7 +252,8 @@ int pb_render_strips_d(pb_ctx* ctx, int first_strip, int strip_stride, int n_str
  * prepared segment set and scene) and its output lives in one file-scope device array of PB_NOALLOC_SCRATCH_BYTES
  * that every GPU the library runs on holds from the first pb_create on it until the process ends.  Frames beyond the
  * maxima below are refused with PB_ERR_CAPACITY and a message naming the limit; the result equals pb_render_d's bit
- * for bit.  All contexts of a GPU share that array and it keeps the last call's contents (the call clears what it
+ * for bit (PB_MODE_73HET: pb_render_d's under pb_set_precise(ctx, 1) - the array has no room for the per-ray walk
+ * tables of the relaxed-arithmetic estimator, so this entry point always runs the exact-order one).  All contexts of a GPU share that array and it keeps the last call's contents (the call clears what it
  * needs zeroed), so calls that overlap in time on one GPU - other streams, other threads - race: issue them one
  * after the other.  The first frame of a given (segment set, rectangle, mode) waits once on `stream` to read two
  * counters back (how many list entries and evaluation items the frame has); later frames of it do not. */
@@ -266,7 +267,12 @@ int pb_render_noalloc_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, flo
  * square root, entry/exit distances taken from the ray parameter; agrees with the reference to its own
  * float rounding noise (well inside max-abs 2e-3*max(1,|ref|), RMSE 1e-4).  1: every operation of
  * HitCylinder / Integral_721 in the reference's order with IEEE divide and sqrt (about 3x slower).
- * The gate (HitBoundingBox + max_distance) is exact in both. */
+ * The gate (HitBoundingBox + max_distance) is exact in both.
+ * PB_MODE_73 / PB_MODE_73HET through the screen-space bins (use_lbvh = 2): 0 takes the closest approach of beam and
+ * view ray from the roots of the cylinder crossing in float and the view ray's mean extinction from a walk through
+ * the grid done once per ray and frame; pairs whose bounds float arithmetic cannot decide safely (a beam seen
+ * end-on, a closest approach at a cap, a grid corner crossed by two axes at once) are evaluated in the reference's
+ * order in double, as every pair is under 1 (about 2x slower).  Same tolerance. */
 int pb_set_precise(pb_ctx* ctx, int on);
 
 /* PutPixelSDL (SDLauxiliary.h:149-161): RGB float -> 0x80RRGGBB, n pixels. */

@@ -11,6 +11,7 @@
 
 #include "pb_internal.h"
 #include "pb_scan.h"
+#include "pb_grid.h"
 
 static thread_local std::string g_last_error;
 void pb_set_error(const std::string& msg) { g_last_error = msg; }
@@ -108,7 +109,8 @@ int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
   if (ctx->d_capB) PB_HIP(hipFree(ctx->d_capB));
   if (ctx->d_het) PB_HIP(hipFree(ctx->d_het));
   if (ctx->d_het_axis) PB_HIP(hipFree(ctx->d_het_axis));
-  ctx->d_het = nullptr; ctx->d_het_axis = nullptr;
+  if (ctx->d_het_fast) PB_HIP(hipFree(ctx->d_het_fast));
+  ctx->d_het = nullptr; ctx->d_het_axis = nullptr; ctx->d_het_fast = nullptr;
   ctx->d_segs = nullptr; ctx->d_frames = nullptr; ctx->d_capA = nullptr; ctx->d_capB = nullptr; ctx->cap_seg = 0;
   PB_HIP(hipMalloc(&ctx->d_segs, sizeof(pb_segment) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_frames, sizeof(SegFrame) * (size_t)cap));
@@ -116,6 +118,7 @@ int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
   PB_HIP(hipMalloc(&ctx->d_capB, sizeof(float4) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_het, sizeof(HetFrame) * (size_t)cap));
   PB_HIP(hipMalloc(&ctx->d_het_axis, sizeof(BeamAxis) * (size_t)cap));
+  PB_HIP(hipMalloc(&ctx->d_het_fast, sizeof(HetFast) * (size_t)cap));
   ctx->cap_seg = cap;
   return PB_OK;
 }
@@ -132,8 +135,9 @@ int default_mode(const pb_ctx* ctx) {
 
 int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
   PB_HIP(hipEventRecord(ctx->ev[2], s));
-  int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.one_dimensional, ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA,
-                                      ctx->d_capB, ctx->d_het, s);
+  int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.one_dimensional, ctx->ctl.scattering_c,
+                                      ctx->ctl.absorption_c + ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA, ctx->d_capB, ctx->d_het,
+                                      ctx->d_het_fast, s);
   if (rc != PB_OK) return rc;
   if (mode != PB_MODE_721) {     // the estimators that go through Integral_73 / Integral_73Het
     rc = pb_launch_beam_axis(ctx->d_capA, ctx->d_capB, ctx->d_het, ctx->n_seg, ctx->d_het_axis, s);
@@ -259,6 +263,17 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     rc = ensure_bin_workspace(ws, slots, want_bins, want_items, px);
     if (rc != PB_OK) return rc;
     p.rays = ws.d_rays; p.group_last = ws.d_group_last; p.ctrl = ws.d_ctrl;
+    p.walk = nullptr;
+    if (mode == PB_MODE_73HET && p.grid_z && !p.precise && !ws.fixed && p.grid_side <= VIEW_WALK_MAX_SIDE) {
+      // the relaxed-arithmetic estimator walks every view ray through the grid once per frame
+      if (groups > ws.ws_walk_groups) {
+        if (ws.d_walk) PB_HIP(hipFree(ws.d_walk));
+        ws.d_walk = nullptr; ws.ws_walk_groups = 0;
+        PB_HIP(hipMalloc(&ws.d_walk, sizeof(float) * VIEW_WALK_STRIDE * 64 * (size_t)groups));
+        ws.ws_walk_groups = groups;
+      }
+      p.walk = ws.d_walk;
+    }
     {
       const size_t T = (size_t)ws.ws_tiles;
       p.tile_count = ws.d_tile_u32; p.item_off = ws.d_tile_u32 + T;
@@ -322,9 +337,12 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       // candidate and drain a partly filled queue at the end of every item: they want longer items (cfg3:
       // 3.37 ms at 48, 3.08 at 96, 2.98 at 128..192, 3.11 at 256; its mean list is about 300).
       const bool queued = mode != PB_MODE_721;
-      int want = (int)(mean_list / (queued ? 2 : 6) + 15) / 16 * 16;
+      // eval_items_het_kernel copies its rays' walk tables and ends with a drain of the pairs it left to the exact-order
+      // code, however few: longer items still (cfg3: 2.09 ms at 96, 1.57 at 192, 1.47 at 256, 1.38 at 384, 1.42 at 512)
+      const bool tabulated = queued && pb_pipelined_eval(p, mode);
+      int want = (int)(mean_list / (tabulated ? 1 : (queued ? 2 : 6)) + 15) / 16 * 16;
       int longest = p.strip_stride >= 8 ? 48 : (p.strip_stride > 1 ? 96 : 128);   // a rank's share of strips has few items
-      if (queued) longest = longest * 3 / 2;
+      if (queued) longest = tabulated ? longest * 3 : longest * 3 / 2;
       const int shortest = queued ? 64 : 48;
       want = want < shortest ? shortest : (want > longest ? longest : want);
       ws.ws_slice = want;
@@ -389,7 +407,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   p.scattering_c = ctx->ctl.scattering_c;
   // Integral_73 reads the grid when HETEROGENEOUS is set (BeamRadiance.h:159-188)
   const bool generic_het = mode == PB_MODE_GENERIC && ctx->ctl.one_dimensional && ctx->ctl.heterogeneous;
-  p.het = ctx->d_het; p.het_axis = ctx->d_het_axis; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side; p.grid_fast_div = ctx->grid_fast_div;
+  p.het = ctx->d_het; p.het_axis = ctx->d_het_axis; p.het_fast = ctx->d_het_fast; p.grid_z = (mode == PB_MODE_73HET || generic_het) ? ctx->d_grid : nullptr; p.grid_side = ctx->grid_side; p.grid_fast_div = ctx->grid_fast_div;
   p.one_dimensional = ctx->ctl.one_dimensional;
   p.short_view = ctx->ctl.short_view; p.view_seed = ctx->ctl.seed;
   p.store_d1 = mode != PB_MODE_721 ? 1 : 0;
@@ -526,10 +544,10 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
-                  ctx->d_het, ctx->d_het_axis, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
+                  ctx->d_het, ctx->d_het_axis, ctx->d_het_fast, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
                   ctx->d_emit_tmp[1], ctx->ws.d_rays, ctx->ws.d_group_last,
                   ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list, ctx->ws.d_blk,
-                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->lb_pool};
+                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->ws.d_walk, ctx->lb_pool};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);

@@ -124,6 +124,127 @@ struct DdaWalk {
   }
 };
 
+// The walk of a view ray from the camera at (0, 0, 0), done once per ray instead of once per (ray, beam) pair.  The
+// return value of Extinction3D for the ray cut at distance s is
+//   (sample at 0 + the crossing samples with t <= s + the closing sample at s) / (their number),
+// and which crossings there are, in which cells, does not depend on s.  view_walk_tabulate walks the ray once with
+// DdaWalk (the reference's float operations, so that crossings of two axes at one lattice corner - common, since
+// pixel directions have rational slopes - are taken in the reference's order and sampled in the reference's cells)
+// and keeps, per axis, the running sums of its crossing samples.  view_walk_mean then needs the number of crossings
+// of each axis up to s (they lie at regular distances t0 + j / rate), three table look-ups and the closing sample.
+// The walk ends at the crossing that takes the x or y cell index outside the grid (Heterogeneous.h:117-120); no
+// later crossing of any axis is sampled, which the per-axis limits `cap` reproduce.
+constexpr int VIEW_WALK_XY = 16;     // table rows per lateral axis: running sums of 0..15 crossings (side <= 30)
+constexpr int VIEW_WALK_Z = 8;       // and along z (cells are 1 deep: 7 crossings reach z = 5)
+constexpr int VIEW_WALK_ROWS = 2 * VIEW_WALK_XY + VIEW_WALK_Z;
+constexpr int VIEW_WALK_MAX_SIDE = 30;
+constexpr int VIEW_WALK_PARAMS = 11;                                   // rows after the tables: ViewWalk's members
+constexpr int VIEW_WALK_STRIDE = VIEW_WALK_ROWS + VIEW_WALK_PARAMS;    // rows of 64 floats per ray group
+
+struct ViewWalk {
+  float t0[3], rate[3];   // distance of an axis' first crossing, crossings per unit distance
+  float cap[3];           // crossings of the axis that the walk sampled
+  float e0;               // the sample at distance 0
+  float t_unsure;         // distance of the first crossing whose order the tabulated walk cannot vouch for
+};
+
+// sigma_t at grid coordinates (px, py) = position - grid_min, read in cell (ix, iy) as DdaWalk::sample reads it.
+PB_DI float grid_sigma_in_cell(const GridView& g, float px, float py, float ix, float iy, float cell, float rcell) {
+  const float top = (float)(g.side - 1);
+  const float cx = __builtin_amdgcn_fmed3f(ix, 0.0f, top), cy = __builtin_amdgcn_fmed3f(iy, 0.0f, top);
+  const float prop_x = fabsf(px - cell * cx) * rcell, prop_y = fabsf(py - cell * cy) * rcell;
+  const float4 c = g.cells()[(int)cy * g.side + (int)cx];
+  const float left = c.x + ((c.y - c.x) * prop_y);
+  const float right = c.z + ((c.w - c.z) * prop_y);
+  return fmaxf(left + ((right - left) * prop_x), 0.0f);
+}
+
+// l: the ray's unit direction.  tab: VIEW_WALK_ROWS rows of 64 floats in LDS, this lane's column.
+PB_DI ViewWalk view_walk_tabulate(const GridView& g, V3 l, float* tab, int lane) {
+  ViewWalk w;
+  DdaWalk d;
+  d.begin(g, v3(0.0f, 0.0f, 0.0f), l * 64.0f);          // far beyond the scene: the walk ends by leaving the grid
+  w.t0[0] = d.tx; w.t0[1] = d.ty; w.t0[2] = d.tz;
+  w.rate[0] = 1.0f / d.delta.x; w.rate[1] = 1.0f / d.delta.y; w.rate[2] = 1.0f / d.delta.z;
+  w.e0 = d.sample(g, 0.0f, d.idx);
+  float n[3] = {0.0f, 0.0f, 0.0f}, run[3] = {0.0f, 0.0f, 0.0f};
+  tab[0 * 64 + lane] = 0.0f; tab[VIEW_WALK_XY * 64 + lane] = 0.0f; tab[2 * VIEW_WALK_XY * 64 + lane] = 0.0f;
+  // Two axes often cross at one lattice corner (pixel directions have rational slopes), and the cells in which the
+  // two samples are read depend on which axis steps first.  The reference walks each pair's ray along
+  // normalize(d1 * distance), which differs from l in the last bits from pair to pair: where the two crossing
+  // distances are closer than that noise the order is the pair's own, and pairs cut beyond that point are left to
+  // the exact-order code.  A tie of x and y on a diagonal ray is exact for every pair (y steps first).
+  w.t_unsure = 3.0e38f;
+  const bool diagonal = fabsf(l.x) == fabsf(l.y);
+  bool alive = true;
+  for (int step = 0; step < VIEW_WALK_ROWS - 3; ++step) {
+    {
+      const float first = fminf(d.tx, fminf(d.ty, d.tz)), second = __builtin_amdgcn_fmed3f(d.tx, d.ty, d.tz);
+      const bool xy = (d.tz > second) || (d.tz > first && d.tx == d.ty);
+      if (alive && (second - first) <= 1e-6f * second && !(diagonal && xy && d.tx == d.ty)) {
+        // The order matters only through the cell in which the first of the two samples is read: the cell entered
+        // by stepping one axis, or the other.  Where both read the same value at this point (all corners of a
+        // cell but the one DdaWalk::sample reads from the wrong lattice point) either order gives the same mean.
+        const float sgx = (d.dir.x < 0) ? -1.0f : 1.0f, sgy = (d.dir.y < 0) ? -1.0f : 1.0f;
+        const bool x_in = d.tx <= second, y_in = d.ty <= second;      // the two axes of the tie (z cells do not enter a sample)
+        V3 ia = d.idx, ib = d.idx;
+        if (x_in && y_in) { ia.x += sgx; ib.y += sgy; }
+        else if (x_in) ia.x += sgx;
+        else ia.y += sgy;
+        const float ea = d.sample(g, first, ia), eb = d.sample(g, first, ib);
+        if (fabsf(ea - eb) > 1e-4f) w.t_unsure = fminf(w.t_unsure, first);
+      }
+    }
+    const V3 before = d.idx;
+    float t;
+    const bool done = d.advance(t);
+    alive = alive && !done;
+    const int axis = (d.idx.x != before.x) ? 0 : ((d.idx.y != before.y) ? 1 : 2);
+    const float limit = (axis == 2) ? (float)(VIEW_WALK_Z - 1) : (float)(VIEW_WALK_XY - 1);
+    const float na = (axis == 0) ? n[0] : ((axis == 1) ? n[1] : n[2]);
+    alive = alive && (na < limit);                      // a full table ends the tabulated part of the walk
+    if (alive) {
+      const float e = d.sample(g, t, d.idx);
+      const int row = (axis == 0) ? 0 : ((axis == 1) ? VIEW_WALK_XY : 2 * VIEW_WALK_XY);
+      const float sum = ((axis == 0) ? run[0] : ((axis == 1) ? run[1] : run[2])) + e;
+      tab[(row + (int)na + 1) * 64 + lane] = sum;
+      if (axis == 0) { run[0] = sum; n[0] += 1.0f; } else if (axis == 1) { run[1] = sum; n[1] += 1.0f; } else { run[2] = sum; n[2] += 1.0f; }
+    }
+  }
+  w.cap[0] = n[0]; w.cap[1] = n[1]; w.cap[2] = n[2];
+  return w;
+}
+
+PB_DI void view_walk_store(const ViewWalk& w, float* rows, int lane) {
+  for (int k = 0; k < 3; ++k) { rows[k * 64 + lane] = w.t0[k]; rows[(3 + k) * 64 + lane] = w.rate[k]; rows[(6 + k) * 64 + lane] = w.cap[k]; }
+  rows[9 * 64 + lane] = w.e0; rows[10 * 64 + lane] = w.t_unsure;
+}
+PB_DI ViewWalk view_walk_load(const float* rows, int lane) {
+  ViewWalk w;
+  for (int k = 0; k < 3; ++k) { w.t0[k] = rows[k * 64 + lane]; w.rate[k] = rows[(3 + k) * 64 + lane]; w.cap[k] = rows[(6 + k) * 64 + lane]; }
+  w.e0 = rows[9 * 64 + lane]; w.t_unsure = rows[10 * 64 + lane];
+  return w;
+}
+
+// Extinction3D's mean for the ray cut at distance s (the walk's t_max).
+PB_DI float view_walk_mean(const GridView& g, const ViewWalk& w, V3 l, float s, const float* tab, int lane) {
+  const float res = (float)(g.side - 1);
+  const float cell = 2.0f / res, rcell = 1.0f / cell;
+  float n[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float c = floorf((s - w.t0[k]) * w.rate[k]) + 1.0f;       // crossing j lies at t0 + j / rate
+    n[k] = __builtin_amdgcn_fmed3f(c, 0.0f, w.cap[k]);              // NaN (an axis the ray runs along): none
+  }
+  // the closing sample: at s, in the cell the walk stands in
+  const float fx0 = floorf(1.0f / cell), fy0 = fx0;
+  const float ix = fx0 + ((l.x < 0) ? -n[0] : n[0]), iy = fy0 + ((l.y < 0) ? -n[1] : n[1]);
+  const float e_end = grid_sigma_in_cell(g, 1.0f + l.x * s, 1.0f + l.y * s, ix, iy, cell, rcell);
+  const float sum = w.e0 + tab[(int)n[0] * 64 + lane] + tab[(VIEW_WALK_XY + (int)n[1]) * 64 + lane] +
+                    tab[(2 * VIEW_WALK_XY + (int)n[2]) * 64 + lane] + e_end;
+  return sum * __builtin_amdgcn_rcpf(n[0] + n[1] + n[2] + 2.0f);
+}
+
 // Return value of Extinction3D: the plain mean of all samples (Heterogeneous.h:182-184).
 PB_DI float extinction3d_mean(const GridView& g, V3 start, V3 end) {
   DdaWalk w;

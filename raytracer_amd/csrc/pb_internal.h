@@ -67,6 +67,16 @@ struct __attribute__((aligned(32))) HetFrame {
 };
 static_assert(sizeof(HetFrame) == 32, "HetFrame layout");
 
+// What the relaxed-arithmetic Integral_73 / Integral_73Het reads of a segment beyond its cylinder frame, in that
+// frame's units (lengths divided by |end - start|; start is its origin, the axis its y): 8 dwords, one scalar load.
+//   orig_start sits at (x, osy, z) with x^2 + z^2 = r2; aos / bos are its distances from start and end;
+//   the beam's extinction at distance beta from orig_start is A + B (beta - aos) (BeamRadiance.h:262-266 with
+//   proportion = (beta - aos) / (bos - aos)); krad = (sigma_s / sigma_t) / radius (:283-285).
+struct __attribute__((aligned(32))) HetFast {
+  float r2, osy, aos, bos, A, B, krad, pad;
+};
+static_assert(sizeof(HetFast) == 32, "HetFast layout");
+
 // What Integral_73Het computes from the segment alone, in double: the unit axis, its dot product with itself, and
 // the distances of the two end points from orig_start.  Filled once per prepared segment set (beam_axis in
 // pb_pair.h) so that the per-hit code does not repeat three square roots and three divisions.
@@ -115,6 +125,8 @@ struct RenderParams {
   float scattering_c;      // Control.h:47
   const HetFrame* het;     // per segment: Integral_73/73Het inputs, or a ConeFrame where qflags bit 5 is set
   const BeamAxis* het_axis; // per segment: beam_axis() of its end points (unused values for a cone record)
+  const HetFast* het_fast;  // per segment, PB_MODE_73 / PB_MODE_73HET: what the relaxed-arithmetic estimator reads
+  float* walk;              // [groups][VIEW_WALK_STRIDE][64] the view rays' tabulated walks through the grid, or null
   int one_dimensional;     // ONE_DIMENSIONAL, read by PB_MODE_GENERIC
   int short_view;          // SHORT_VIEW
   uint32_t view_seed;      // Control seed: key of the camera rays' draws
@@ -212,6 +224,8 @@ struct FrameWorkspace {
   uint32_t* d_items = nullptr;
   unsigned long long* d_accum = nullptr;
   uint32_t* d_scan_tmp = nullptr;
+  float* d_walk = nullptr;             // per ray group: the view rays' tabulated grid walks (heterogeneous medium only)
+  int ws_walk_groups = 0;
   int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_items_needed = 0;
   size_t ws_accum_px = 0;
   unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // segment set + frame geometry the capacities were verified for
@@ -250,6 +264,7 @@ struct pb_ctx {
   float4* d_capB = nullptr;
   HetFrame* d_het = nullptr;
   BeamAxis* d_het_axis = nullptr;
+  HetFast* d_het_fast = nullptr;
   // extinction field of the heterogeneous medium
   float* d_grid = nullptr;
   int grid_side = 0;
@@ -309,8 +324,8 @@ int pb_lbvh_download(pb_ctx* ctx, uint64_t* keys, uint32_t* perm, pb_node* nodes
 // launchers implemented in the kernel translation units
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* matrix16, TriPrep* d_out,
                             float4* d_screen_box, float* d_screen_edge, hipStream_t s);
-int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int one_dimensional, float scattering_c, SegFrame* d_frames,
-                               float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s);
+int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int one_dimensional, float scattering_c, float extinction_c,
+                               SegFrame* d_frames, float4* d_capA, float4* d_capB, HetFrame* d_het, HetFast* d_het_fast, hipStream_t s);
 int pb_launch_beam_axis(const float4* d_capA, const float4* d_capB, const HetFrame* d_het, int n, BeamAxis* d_out, hipStream_t s);
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_eval_reduce(const RenderParams& p, int mode, bool count, hipStream_t s);

@@ -492,6 +492,67 @@ PB_DI bool pair_721_fast_gate(const float lo[3], const float hi[3], const float 
   return true;
 }
 
+// The cylinder crossing for the relaxed-arithmetic Integral_73 / Integral_73Het, from the first sixteen dwords of the
+// segment's record.  In the cylinder's frame the view ray's closest approach to the axis is at the mid-point of the
+// two roots, t_mid = -b / 2a, where the axis point is y_star (in units of the segment's length from its start).
+// That is the pair of points Integral_73Het finds by solving for the closest approach of the two lines in double
+// (BeamRadiance.h:224-243); its bound on the view distance (:247, between the entry and the exit point) reads
+// th_first <= t_mid <= th_second here.  sin^2(theta) between beam and view ray is a = dpx^2 + dpz^2 (R_inv is a
+// rotation and l a unit vector), free of the cancellation in 1 - cos^2.
+// This estimator is a box across the beam: a pair contributes in full or not at all, so a bound decided the other
+// way than the reference decides it costs a whole term.  Where the decision is not safe in float arithmetic the pair
+// is handed to the exact-order code instead (return value 3):
+//  * the discriminant is computed with the operations of hit_cylinder_exact, so a cylinder is hit here exactly when
+//    it is hit there;
+//  * a beam seen nearly end-on (a < HET_FAST_MIN_SIN2): the closest approach is ill-conditioned and 1 / sin(theta) large;
+//  * t_mid within HET_FAST_EDGE (relative) of th_first or th_second, or within what the rounding of a short and
+//    distant segment's coordinates can move them (y_err_out: the same margin for the axis point's y).
+// Returns 0 = no cylinder hit, 1 = nothing to integrate, 2 = a crossing whose closest approach lies inside it, 3 = undecided.
+constexpr float HET_FAST_MIN_SIN2 = 0.01f;
+constexpr float HET_FAST_EDGE = 5e-5f;
+PB_DI int pair_het_fast_geometry(const float Rinv[9], float ox2, float oz2, float c4, float oy, float len, const Ray& r,
+                                 float& tc_minus_out, float& t_mid_out, float& y_star_out, float& y_err_out, float& sin2_out) {
+  const V3 l = r.l;
+  const float dpx = Rinv[0] * l.x + Rinv[3] * l.y + Rinv[6] * l.z;
+  const float dpz = Rinv[2] * l.x + Rinv[5] * l.y + Rinv[8] * l.z;
+  const float a = dpx * dpx + dpz * dpz;
+  const float b = ox2 * dpx + oz2 * dpz;
+  const float b24ac = b * b - a * c4;
+  if (b24ac < 0) return 0;
+  if (!(a >= HET_FAST_MIN_SIN2)) return 3;
+  const float sq = __builtin_amdgcn_sqrtf(b24ac);
+  const float inv2a = fast_rcp(a + a);
+  const float t0 = (-b - sq) * inv2a;
+  const float t1 = (-b + sq) * inv2a;
+  if (!((t0 > 0) && (t1 > t0))) return 1;
+  const float dpy = __builtin_fmaf(Rinv[7], l.z, __builtin_fmaf(Rinv[4], l.y, Rinv[1] * l.x));
+  const float y0 = __builtin_fmaf(t0, dpy, oy);
+  const float y1 = __builtin_fmaf(t1, dpy, oy);
+  // y is the difference of two numbers that are large where the segment is short against its distance from the
+  // camera (the frame's unit is the segment's length): its rounding error, generously
+  const float y_err = 2e-6f * (fabsf(oy) + fabsf(t1 * dpy));
+  if (fmaxf(y0, y1) < -y_err || fminf(y0, y1) > 1.0f + y_err) return 1;
+  const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);
+  const float sy = __builtin_amdgcn_fmed3f(y1, 0.0f, 1.0f);
+  const float q = -fast_rcp(dpy);
+  const float thf = t0 + mul_zero_wins(y0 - fy, q);
+  const float ths = t1 + mul_zero_wins(y1 - sy, q);
+  const float t_mid = -b * inv2a;
+  tc_minus_out = thf * len;
+  // The reference takes the view ray's direction from the entry and exit points it has rounded to float: over a chord
+  // of relative length (ths - thf) / t_mid that direction is off by about 1e-7 t_mid / (ths - thf), which moves the
+  // closest approach by that angle over sin^2(theta) - for a sliver of a segment far more than any fixed margin.
+  const float noise = 2.5e-7f * t_mid * fast_rcp(fmaxf(ths - thf, 1e-30f) * a);
+  const float edge = fmaxf(HET_FAST_EDGE, noise) * t_mid + y_err * fabsf(q);
+  y_err_out = y_err + edge;                              // y moves by at most |dpy| <= 1 per unit of t
+  if (t_mid < thf - edge || t_mid > ths + edge) return 1;
+  if (t_mid < thf + edge || t_mid > ths - edge) return 3;
+  t_mid_out = t_mid;
+  y_star_out = __builtin_fmaf(t_mid, dpy, oy);
+  sin2_out = a;
+  return 2;
+}
+
 // log2_scale: the integral is returned times 2^log2_scale (folded into the exponential at no cost).
 template <bool CHECK>
 PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong,

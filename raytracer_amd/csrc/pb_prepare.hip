@@ -115,8 +115,8 @@ __device__ float box_reach(const float lo[3], const float hi[3], V3 a, V3 b) {
 }
 
 __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int n, int mode, int one_dimensional, float scattering_c,
-                                        SegFrame* __restrict__ frames, float4* __restrict__ capA,
-                                        float4* __restrict__ capB, HetFrame* __restrict__ het) {
+                                        float extinction_c, SegFrame* __restrict__ frames, float4* __restrict__ capA,
+                                        float4* __restrict__ capB, HetFrame* __restrict__ het, HetFast* __restrict__ het_fast) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const pb_segment s = segs[i];
@@ -215,6 +215,25 @@ __global__ void prepare_segments_kernel(const pb_segment* __restrict__ segs, int
   h.seg_id = s.seg_id; h.radius = s.radius;
   if (cone) *reinterpret_cast<ConeFrame*>(&het[i]) = cf;
   else het[i] = h;
+  if (het_fast && (mode == PB_MODE_73 || mode == PB_MODE_73HET)) {
+    // orig_start in the cylinder's frame (start is its origin): R_inv (orig_start - start) S_inv
+    const V3 q = mul(Rinv, ostart - start) * Sinv;
+    HetFast hf;
+    hf.r2 = q.x * q.x + q.z * q.z;
+    hf.osy = q.y;
+    hf.aos = pb_sqrt(hf.r2 + q.y * q.y);
+    hf.bos = pb_sqrt(hf.r2 + (1.0f - q.y) * (1.0f - q.y));
+    if (mode == PB_MODE_73HET) {
+      // beam_extinction = c_ext + (s_ext + (e_ext - s_ext) proportion - c_ext) / (seg_id + 1), linear in proportion
+      const float inv_seg = 1.0f / (float)(s.seg_id + 1);
+      const float span = hf.bos - hf.aos;
+      hf.A = s.c_ext + (s.s_ext - s.c_ext) * inv_seg;
+      hf.B = span != 0.0f ? (s.e_ext - s.s_ext) * inv_seg / span : 0.0f;
+    } else { hf.A = extinction_c; hf.B = 0.0f; }
+    hf.krad = (scattering_c / extinction_c) / s.radius;
+    hf.pad = 0.0f;
+    het_fast[i] = hf;
+  }
 }
 
 int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_matrix16, TriPrep* d_out,
@@ -225,11 +244,11 @@ int pb_launch_prepare_scene(const float* d_tri_xyz, int n_tri, const float* d_ma
   return PB_OK;
 }
 
-int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int one_dimensional, float scattering_c, SegFrame* d_frames,
-                               float4* d_capA, float4* d_capB, HetFrame* d_het, hipStream_t s) {
+int pb_launch_prepare_segments(const pb_segment* d_segs, int n, int mode, int one_dimensional, float scattering_c, float extinction_c,
+                               SegFrame* d_frames, float4* d_capA, float4* d_capB, HetFrame* d_het, HetFast* d_het_fast, hipStream_t s) {
   if (n <= 0) return PB_OK;
   hipLaunchKernelGGL(prepare_segments_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_segs, n, mode, one_dimensional,
-                     scattering_c, d_frames, d_capA, d_capB, d_het);
+                     scattering_c, extinction_c, d_frames, d_capA, d_capB, d_het, d_het_fast);
   PB_HIP(hipGetLastError());
   return PB_OK;
 }

@@ -187,7 +187,8 @@ extern "C" int pb_probe_pairs(pb_ctx* ctx, const pb_segment* segs, const float* 
   double* d_int = out.as<double>(); float* d_cyl = (float*)(d_int + nn); int* d_status = (int*)(d_cyl + 12 * nn);
   PB_HIP(hipMemcpyAsync(d_segs, segs, sizeof(pb_segment) * nn, hipMemcpyHostToDevice, s));
   PB_HIP(hipMemcpyAsync(d_dir, dir_xyzw, sizeof(float) * 4 * nn, hipMemcpyHostToDevice, s));
-  int rc = pb_launch_prepare_segments(d_segs, n, mode, ctx->ctl.one_dimensional, ctx->ctl.scattering_c, d_frames, d_capA, d_capB, d_het, s);
+  int rc = pb_launch_prepare_segments(d_segs, n, mode, ctx->ctl.one_dimensional, ctx->ctl.scattering_c,
+                                      ctx->ctl.absorption_c + ctx->ctl.scattering_c, d_frames, d_capA, d_capB, d_het, nullptr, s);
   if (rc != PB_OK) return rc;
   GridView g;
   const bool generic_het = mode == PB_MODE_GENERIC && ctx->ctl.one_dimensional && ctx->ctl.heterogeneous && ctx->d_grid;

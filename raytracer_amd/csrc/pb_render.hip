@@ -367,6 +367,7 @@ __global__ __launch_bounds__(CULL_THREADS) void cull_lbvh_block_kernel(const Ren
 // which makes three dependent round trips to L2 per candidate.  WHOLE = false fetches the 32 dwords the
 // fast evaluation reads.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 template <bool WHOLE>
 PB_DI SegFrame fetch_frame(const SegFrame* frames, int sidx) {
   const PB_CONST_AS u32x16* src = (const PB_CONST_AS u32x16*)pb_uniform(frames + sidx);
@@ -1287,79 +1288,11 @@ PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t 
   }
 }
 
+// What an evaluation item does with its lane sums: adds them to its tile's accumulators and, where the frame has no
+// write-out launch of its own, writes the tile's pixels if it is the last of the tile's items to arrive.
 template <bool FINALIZE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_items_fast_kernel(const RenderParams p) {
-  __shared__ uint32_t surv[PB_SLICE];
-  const int lane = threadIdx.x;
-  const uint32_t produced = p.ctrl[0];
-  const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
-  // Workgroups go round the eight XCDs by their index, and each XCD has an L2 of its own: the items of one tile, which
-  // are neighbours in the queue and read the same rays and much the same records, are kept on one XCD by handing out
-  // the queue in runs of xcd_run items (the runs still go round the XCDs, longest lists first).
-  uint32_t c = blockIdx.x;
-  if (p.xcd_run > 0) {
-    const uint32_t run_len = (uint32_t)p.xcd_run, xcd = c & 7u, j = c >> 3;
-    c = ((j / run_len) * 8u + xcd) * run_len + j % run_len;
-  }
-  if (c >= n_items) return;
+PB_DI void item_writeout(const RenderParams& p, int tile, int lane, const PairSums& sum) {
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
-  const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
-  const int group = (int)it[0];
-  const uint32_t start = it[1];
-  const int cn = (int)it[2];
-  const int tile = group / (p.ssaa * p.ssaa);
-  const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
-  V3 pl[4];
-  {
-    const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
-    pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
-  }
-  Ray r;
-  r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
-  r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
-  r.maxd = rr[6 * 64 + lane];
-  r.d1 = r.dn;
-  r.active = r.maxd >= 0.0f;
-  // 1. lanes test the candidates against this tile's pyramid, 64 at a time; survivors are compacted into LDS
-  int ns = 0;
-  for (int base = 0; base < cn; base += 64) {
-    const int k = base + lane;
-    const uint32_t cand = (k < cn) ? p.bin_list[start + k] : 0xffffffffu;
-    bool touch = false;
-    if (cand != 0xffffffffu) touch = axis_touches_pyramid(p.capA[cand], p.capB[cand], pl);
-    const unsigned long long mask = __ballot(touch);
-    if (touch) surv[ns + (int)lanes_below(mask)] = cand;
-    ns += __builtin_popcountll(mask);
-  }
-  __syncthreads();
-  // A SIMD shares its issue slots among up to eight items, and the kernel ends with its longest one: items with many
-  // survivors go first in the SIMD's arbitration, the short ones fill the slots they leave.
-  if (ns > 32) __builtin_amdgcn_s_setprio(3);
-  else if (ns > 16) __builtin_amdgcn_s_setprio(2);
-  else if (ns > 8) __builtin_amdgcn_s_setprio(1);
-  // 2. every lane evaluates its own ray against each survivor
-  PairSums sum;
-  sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = sum.ng = 0u;
-  const SegFrame* frames = p.frames;
-  const float extinction = p.extinction_c;
-  for (int b0 = 0; b0 < ns; b0 += 64) {
-    const int nb = (ns - b0) < 64 ? (ns - b0) : 64;
-    const int mine = (lane < nb) ? (int)surv[b0 + lane] : 0;
-    uint32_t off_cur = (uint32_t)__builtin_amdgcn_readlane(mine, 0) * (uint32_t)sizeof(SegFrame);
-    u32x16 ra, rb;
-    smem_load16(ra, frames, off_cur);
-    smem_wait(ra);
-    int k = 0;
-    for (; k + 1 < nb; k += 2) {
-      const uint32_t off1 = (uint32_t)__builtin_amdgcn_readlane(mine, k + 1) * (uint32_t)sizeof(SegFrame);
-      const int k2 = (k + 2 < nb) ? k + 2 : nb - 1;
-      const uint32_t off2 = (uint32_t)__builtin_amdgcn_readlane(mine, k2) * (uint32_t)sizeof(SegFrame);
-      pair_step(frames, ra, rb, off_cur, off1, r, extinction, sum);
-      pair_step(frames, rb, ra, off1, off2, r, extinction, sum);
-      off_cur = off2;
-    }
-    if (k < nb) pair_step(frames, ra, rb, off_cur, off_cur, r, extinction, sum);
-  }
   unsigned long long* dst = p.accum + (size_t)tile * PB_ACC_PLANES * 64 + lane;
   // A segment whose beam has met no coloured wall weighs the three channels alike (most do): its terms go to the
   // tile's fourth plane, one atomic instruction instead of three; the pixel write-out adds that plane to each channel.
@@ -1420,6 +1353,324 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   }
 }
 
+template <bool FINALIZE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_items_fast_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  const int lane = threadIdx.x;
+  const uint32_t produced = p.ctrl[0];
+  const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
+  // Workgroups go round the eight XCDs by their index, and each XCD has an L2 of its own: the items of one tile, which
+  // are neighbours in the queue and read the same rays and much the same records, are kept on one XCD by handing out
+  // the queue in runs of xcd_run items (the runs still go round the XCDs, longest lists first).
+  uint32_t c = blockIdx.x;
+  if (p.xcd_run > 0) {
+    const uint32_t run_len = (uint32_t)p.xcd_run, xcd = c & 7u, j = c >> 3;
+    c = ((j / run_len) * 8u + xcd) * run_len + j % run_len;
+  }
+  if (c >= n_items) return;
+  const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
+  const int group = (int)it[0];
+  const uint32_t start = it[1];
+  const int cn = (int)it[2];
+  const int tile = group / (p.ssaa * p.ssaa);
+  const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+  V3 pl[4];
+  {
+    const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
+    pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
+  }
+  Ray r;
+  r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+  r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
+  r.maxd = rr[6 * 64 + lane];
+  r.d1 = r.dn;
+  r.active = r.maxd >= 0.0f;
+  // 1. lanes test the candidates against this tile's pyramid, 64 at a time; survivors are compacted into LDS
+  int ns = 0;
+  for (int base = 0; base < cn; base += 64) {
+    const int k = base + lane;
+    const uint32_t cand = (k < cn) ? p.bin_list[start + k] : 0xffffffffu;
+    bool touch = false;
+    if (cand != 0xffffffffu) touch = axis_touches_pyramid(p.capA[cand], p.capB[cand], pl);
+    const unsigned long long mask = __ballot(touch);
+    if (touch) surv[ns + (int)lanes_below(mask)] = cand;
+    ns += __builtin_popcountll(mask);
+  }
+  __syncthreads();
+  // A SIMD shares its issue slots among up to eight items, and the kernel ends with its longest one: items with many
+  // survivors go first in the SIMD's arbitration, the short ones fill the slots they leave.
+  if (ns > 32) __builtin_amdgcn_s_setprio(3);
+  else if (ns > 16) __builtin_amdgcn_s_setprio(2);
+  else if (ns > 8) __builtin_amdgcn_s_setprio(1);
+  // 2. every lane evaluates its own ray against each survivor
+  PairSums sum;
+  sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = sum.ng = 0u;
+  const SegFrame* frames = p.frames;
+  const float extinction = p.extinction_c;
+  for (int b0 = 0; b0 < ns; b0 += 64) {
+    const int nb = (ns - b0) < 64 ? (ns - b0) : 64;
+    const int mine = (lane < nb) ? (int)surv[b0 + lane] : 0;
+    uint32_t off_cur = (uint32_t)__builtin_amdgcn_readlane(mine, 0) * (uint32_t)sizeof(SegFrame);
+    u32x16 ra, rb;
+    smem_load16(ra, frames, off_cur);
+    smem_wait(ra);
+    int k = 0;
+    for (; k + 1 < nb; k += 2) {
+      const uint32_t off1 = (uint32_t)__builtin_amdgcn_readlane(mine, k + 1) * (uint32_t)sizeof(SegFrame);
+      const int k2 = (k + 2 < nb) ? k + 2 : nb - 1;
+      const uint32_t off2 = (uint32_t)__builtin_amdgcn_readlane(mine, k2) * (uint32_t)sizeof(SegFrame);
+      pair_step(frames, ra, rb, off_cur, off1, r, extinction, sum);
+      pair_step(frames, rb, ra, off1, off2, r, extinction, sum);
+      off_cur = off2;
+    }
+    if (k < nb) pair_step(frames, ra, rb, off_cur, off_cur, r, extinction, sum);
+  }
+  item_writeout<FINALIZE>(p, tile, lane, sum);
+}
+
+// Integral_73 / Integral_73Het with relaxed arithmetic, in the same one-wave-per-item shape.  What the exact-order
+// estimator spends its time on - the closest approach of beam axis and view ray in double, and for every valid pair a
+// walk through the grid from the camera to that point - reduces to a few float operations here:
+//  * the closest approach is the mid-point of the cylinder crossing's two roots (pair_het_fast_geometry);
+//  * the walk's result depends on the view ray and on where it is cut only: each item tabulates, per ray, the running
+//    sums of the samples at the crossings of each grid axis (view_walk_tabulate: 37 samples per ray), and a valid pair
+//    then costs three table look-ups and the one sample at its own end point (view_walk_mean);
+//  * transmittance along beam and view ray is one exp2 of the summed optical depths.
+// The frame differs from the exact-order one by float rounding, and by a contribution gained or lost where a
+// closest approach falls within rounding of a cap of its segment; pb_set_precise(ctx, 1) selects the exact-order kernels.
+constexpr int HIT_QUEUE = 128;      // (ray, segment) pairs an item can have waiting in LDS
+struct HetHalf { float r2, osy, aos, bos, A, B, krad, pad; };
+static_assert(sizeof(HetHalf) == sizeof(HetFast), "one scalar load of eight dwords");
+
+PB_DI void smem_load8(u32x8& dst, const HetFast* base, uint32_t byte_offset) {
+  asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(dst) : "s"(base), "s"(byte_offset));
+}
+PB_DI void smem_wait(u32x16& a, u32x16& b, u32x8& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c)); }
+
+struct HetItem {
+  const SegFrame* frames;
+  const HetFast* het;
+  GridView grid;
+  ViewWalk walk;
+  const float* tab;        // this wave's walk tables in LDS
+  float d1_len;            // |d1|: the reference cuts the view ray's walk at d1 * distance, d1 the vec4-normalised direction
+  float extinction;        // sigma_t (the view ray's extinction when there is no grid)
+  int lane;
+  uint32_t* q_seg;         // pairs left to the exact-order code: segment and lane (ray) of each, in LDS
+  uint32_t* q_ray;
+};
+
+// Returns the lanes whose pair the exact-order code has to decide (pair_het_fast_geometry; likewise an axis point
+// within HET_FAST_EDGE of an end of the segment's stretch of the beam).
+PB_DI unsigned long long pair_step_het(const HetItem& h, u32x16& cur, u32x16& nxt, uint32_t idx_cur, uint32_t idx_nxt, const Ray& r,
+                                       PairSums& sum) {
+  const uint32_t off_cur = idx_cur * (uint32_t)sizeof(SegFrame), off_nxt = idx_nxt * (uint32_t)sizeof(SegFrame);
+  u32x16 second;
+  u32x8 third;
+  smem_load16(second, h.frames, off_cur + 64u);
+  smem_load8(third, h.het, idx_cur * (uint32_t)sizeof(HetFast));
+  smem_load16(nxt, h.frames, off_nxt);
+  SegHalfA a;
+  __builtin_memcpy(&a, &cur, 64);
+  float tc_minus = 0.0f, t_mid = 0.0f, y_star = 0.0f, y_err = 0.0f, sin2 = 1.0f;
+  const int res = pair_het_fast_geometry(a.Rinv, a.ox2, a.oz2, a.c4, a.oy, a.len, r, tc_minus, t_mid, y_star, y_err, sin2);
+  smem_wait(second, nxt, third);
+  SegHalfB b;
+  __builtin_memcpy(&b, &second, 64);
+  HetHalf f;
+  __builtin_memcpy(&f, &third, 32);
+  bool ok = res == 2;
+  bool defer = res == 3;
+  if (ok && !pair_721_fast_sure(a.qflags, tc_minus, r.maxd)) ok = pair_721_fast_gate(b.lo, b.hi, b.cand, a.qflags, r);
+  if (ok) {
+    // distance of the axis point from orig_start, within [|start - orig_start|, |end - orig_start|] (BeamRadiance.h:248)
+    const float dy = y_star - f.osy;
+    const float beta = __builtin_amdgcn_sqrtf(__builtin_fmaf(dy, dy, f.r2));
+    const float edge = HET_FAST_EDGE * f.bos + y_err;
+    ok = (beta >= f.aos + edge) && (beta <= f.bos - edge);
+    defer = !ok && (beta >= f.aos - edge) && (beta <= f.bos + edge);
+    if (ok) {
+      const float view_distance = t_mid * a.len;
+      const float beam_extinction = __builtin_fmaf(f.B, beta - f.aos, f.A);
+      float view_extinction = h.extinction;
+      if (h.grid.z) {
+        const float cut = view_distance * h.d1_len;
+        defer = cut >= h.walk.t_unsure;       // the exact-order code evaluates this pair; the term added below is zero
+        view_extinction = view_walk_mean(h.grid, h.walk, r.l, cut, h.tab, h.lane);
+      }
+      const float depth = __builtin_fmaf(beam_extinction * beta, a.len, view_extinction * view_distance);
+      const float transmitted = __builtin_amdgcn_exp2f(__builtin_fmaf(depth, -1.44269504f, -10.0f));   // times the 2^-10 of the sums
+      float value = transmitted * beam_extinction * f.krad * __builtin_amdgcn_rsqf(sin2);
+      if (transmitted < 1e-6f * 0.0009765625f || defer) value = 0.0f;                                   // BeamRadiance.h:273
+      const double integral = (double)__builtin_amdgcn_fmed3f(value, 0.0f, b.vcap10);
+      if (a.qflags & 64u) {
+        sum.ag += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
+        sum.ng++;
+      } else {
+        sum.ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
+        sum.ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[1], integral, PB_FIX_MAGIC));
+        sum.ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[2], integral, PB_FIX_MAGIC));
+        sum.nc++;
+      }
+    }
+  }
+  return __ballot(defer && r.active);
+}
+
+// One wave per ray group: every lane walks its view ray through the grid once and leaves the running sums of the
+// crossing samples (view_walk_tabulate) for the frame's evaluation items, of which a tile has many.
+__global__ __launch_bounds__(64) void view_walk_kernel(const RenderParams p) {
+  const int group = blockIdx.x, lane = threadIdx.x;
+  const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+  if (pb_uniform(p.group_last)[group] < 0) return;          // no ray of the group is active: no item reads its tables
+  GridView grid;
+  grid.z = p.grid_z; grid.side = p.grid_side; grid.fast_div = p.grid_fast_div;
+  float* wt = p.walk + (size_t)group * VIEW_WALK_STRIDE * 64;
+  const ViewWalk w = view_walk_tabulate(grid, v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]), wt, lane);
+  view_walk_store(w, wt + VIEW_WALK_ROWS * 64, lane);
+}
+
+template <bool FINALIZE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void eval_items_het_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  __shared__ float tab[VIEW_WALK_ROWS * 64];
+  __shared__ uint32_t q_seg[HIT_QUEUE], q_ray[HIT_QUEUE];
+  __shared__ unsigned long long s_acc[3][64];
+  const int lane = threadIdx.x;
+  const uint32_t produced = p.ctrl[0];
+  const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
+  uint32_t c = blockIdx.x;
+  if (p.xcd_run > 0) {
+    const uint32_t run_len = (uint32_t)p.xcd_run, xcd = c & 7u, j = c >> 3;
+    c = ((j / run_len) * 8u + xcd) * run_len + j % run_len;
+  }
+  if (c >= n_items) return;
+  const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
+  const int group = (int)it[0];
+  const uint32_t start = it[1];
+  const int cn = (int)it[2];
+  const int tile = group / (p.ssaa * p.ssaa);
+  const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+  V3 pl[4];
+  {
+    const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
+    pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
+  }
+  Ray r;
+  r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+  r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
+  r.maxd = rr[6 * 64 + lane];
+  r.d1 = v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]);
+  r.active = r.maxd >= 0.0f;
+  int ns = 0;
+  for (int base = 0; base < cn; base += 64) {
+    const int k = base + lane;
+    const uint32_t cand = (k < cn) ? p.bin_list[start + k] : 0xffffffffu;
+    bool touch = false;
+    if (cand != 0xffffffffu) touch = axis_touches_pyramid(p.capA[cand], p.capB[cand], pl);
+    const unsigned long long mask = __ballot(touch);
+    if (touch) surv[ns + (int)lanes_below(mask)] = cand;
+    ns += __builtin_popcountll(mask);
+  }
+  HetItem h;
+  h.frames = p.frames; h.het = p.het_fast;
+  h.grid.z = p.grid_z; h.grid.side = p.grid_side; h.grid.fast_div = p.grid_fast_div;
+  h.tab = tab; h.lane = lane; h.extinction = p.extinction_c;
+  h.q_seg = q_seg; h.q_ray = q_ray;
+  h.d1_len = length3(r.d1);
+  if (ns > 0 && h.grid.z) {
+    // the rays' tabulated walks (view_walk_kernel): members to registers, tables to LDS
+    const float* wt = p.walk + (size_t)group * VIEW_WALK_STRIDE * 64;
+    h.walk = view_walk_load(wt + VIEW_WALK_ROWS * 64, lane);
+#pragma unroll 8
+    for (int row = 0; row < VIEW_WALK_ROWS; ++row) tab[row * 64 + lane] = wt[row * 64 + lane];
+  }
+  s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull;
+  __syncthreads();
+  // The pairs left to the exact-order code wait in LDS until there are 64 of them (or the item ends): every lane then
+  // takes one, whatever ray it belongs to, and adds its term to that ray's sums in LDS.
+  int pending = 0;
+  bool any_exact = false;
+  auto push = [&](unsigned long long mask, uint32_t sidx) {
+    if ((mask >> lane) & 1ull) {
+      const int e = pending + (int)lanes_below(mask);
+      q_seg[e] = sidx; q_ray[e] = (uint32_t)lane;
+    }
+    pending += __builtin_popcountll(mask);
+  };
+  auto drain = [&](int take) {
+    __syncthreads();
+    if (lane < take) {
+      const int e = pending - take + lane;
+      const uint32_t sidx = q_seg[e], rl = q_ray[e];
+      Ray rq;
+      rq.l = v3(rr[0 * 64 + rl], rr[1 * 64 + rl], rr[2 * 64 + rl]);
+      rq.dn = v3(rr[3 * 64 + rl], rr[4 * 64 + rl], rr[5 * 64 + rl]);
+      rq.maxd = rr[6 * 64 + rl];
+      rq.d1 = v3(rr[8 * 64 + rl], rr[9 * 64 + rl], rr[10 * 64 + rl]);
+      rq.active = true;
+      const SegFrame& f = p.frames[sidx];
+      CylHit hit;
+      if (hit_cylinder_exact(f, rq, hit) == 2) {
+        const float4 A = p.capA[sidx];
+        double integral = integral_73het(h.grid, v3(A.x, A.y, A.z), p.het[sidx], p.het_axis[sidx], hit, rq, p.extinction_c, p.scattering_c);
+        const double W0 = f.W[0], W1 = f.W[1], W2 = f.W[2];
+        integral = fmin(integral, PB_FIX_LIMIT / fmax(W0, fmax(W1, W2)));
+        integral = integral * PB_FIX_PRESCALE;
+        const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
+        const unsigned long long v0 = (unsigned long long)__double_as_longlong(__builtin_fma(W0, integral, PB_FIX_MAGIC)) - magic_bits;
+        const unsigned long long v1 = (unsigned long long)__double_as_longlong(__builtin_fma(W1, integral, PB_FIX_MAGIC)) - magic_bits;
+        const unsigned long long v2 = (unsigned long long)__double_as_longlong(__builtin_fma(W2, integral, PB_FIX_MAGIC)) - magic_bits;
+        if (v0) atomicAdd(&s_acc[0][rl], v0);
+        if (v1) atomicAdd(&s_acc[1][rl], v1);
+        if (v2) atomicAdd(&s_acc[2][rl], v2);
+      }
+    }
+    pending -= take;
+    any_exact = true;
+    __syncthreads();
+  };
+  if (ns > 32) __builtin_amdgcn_s_setprio(3);
+  else if (ns > 16) __builtin_amdgcn_s_setprio(2);
+  else if (ns > 8) __builtin_amdgcn_s_setprio(1);
+  PairSums sum;
+  sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = sum.ng = 0u;
+  for (int b0 = 0; b0 < ns; b0 += 64) {
+    const int nb = (ns - b0) < 64 ? (ns - b0) : 64;
+    const int mine = (lane < nb) ? (int)surv[b0 + lane] : 0;
+    uint32_t idx_cur = (uint32_t)__builtin_amdgcn_readlane(mine, 0);
+    u32x16 ra, rb;
+    smem_load16(ra, h.frames, idx_cur * (uint32_t)sizeof(SegFrame));
+    smem_wait(ra);
+    int k = 0;
+    for (; k + 1 < nb; k += 2) {
+      const uint32_t idx1 = (uint32_t)__builtin_amdgcn_readlane(mine, k + 1);
+      const int k2 = (k + 2 < nb) ? k + 2 : nb - 1;
+      const uint32_t idx2 = (uint32_t)__builtin_amdgcn_readlane(mine, k2);
+      const unsigned long long m0 = pair_step_het(h, ra, rb, idx_cur, idx1, r, sum);
+      if (m0) { push(m0, idx_cur); if (pending >= 64) drain(64); }
+      const unsigned long long m1 = pair_step_het(h, rb, ra, idx1, idx2, r, sum);
+      if (m1) { push(m1, idx1); if (pending >= 64) drain(64); }
+      idx_cur = idx2;
+    }
+    if (k < nb) {
+      const unsigned long long m = pair_step_het(h, ra, rb, idx_cur, idx_cur, r, sum);
+      if (m) { push(m, idx_cur); if (pending >= 64) drain(64); }
+    }
+  }
+  if (pending > 0) drain(pending);
+  if (any_exact) {
+    // the exact-order terms carry no anchor: they join the lane's sums as one more term
+    const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
+    const unsigned long long a0 = s_acc[0][lane], a1 = s_acc[1][lane], a2 = s_acc[2][lane];
+    if (a0 | a1 | a2) {
+      sum.ai[0] += a0 + magic_bits; sum.ai[1] += a1 + magic_bits; sum.ai[2] += a2 + magic_bits;
+      sum.nc++;
+    }
+  }
+  item_writeout<FINALIZE>(p, tile, lane, sum);
+}
+
 // Frames of the estimators whose integral is long: Integral_73Het / Integral_73 (closest approach in double, a
 // walk through the grid along the view ray) and BeamRadiance's dispatch (Integral_721_ada's Riemann sum).  About
 // one candidate-lane pair in four is a valid hit, so evaluating the integral inside the pair loop leaves most
@@ -1427,7 +1678,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // LDS; whenever 64 are waiting every lane takes one, evaluates the integral and adds the result to its ray's
 // sums in LDS.  The sums are fixed point, so the order of the additions does not matter and the frame equals
 // eval_bins_kernel's bit for bit.
-constexpr int HIT_QUEUE = 128;
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void eval_bins_queue_kernel(const RenderParams p) {
   constexpr bool GENERIC = MODE == PB_MODE_GENERIC;
@@ -1586,8 +1836,12 @@ int pb_fused_queue_macros(void) { return QUEUE_FUSED_MACROS; }
 
 // Whether an uncounted frame of `mode` is evaluated by eval_items_fast_kernel (one wave per item, 32-bit record offsets).
 bool pb_pipelined_eval(const RenderParams& p, int mode) {
-  return mode == PB_MODE_721 && !p.precise && p.eval_waves <= 0 && (size_t)p.n_seg * sizeof(SegFrame) < ((size_t)1 << 31) &&
-         !std::getenv("PB_OLD_EVAL");
+  if (p.precise || p.eval_waves > 0 || (size_t)p.n_seg * sizeof(SegFrame) >= ((size_t)1 << 31) || std::getenv("PB_OLD_EVAL")) return false;
+  if (mode == PB_MODE_721) return true;
+  // eval_items_het_kernel: its walk tables hold the crossings of a grid of at most VIEW_WALK_MAX_SIDE points a side
+  if (mode == PB_MODE_73 || mode == PB_MODE_73HET)
+    return p.het_fast && (!p.grid_z || (p.walk && p.grid_side >= 2 && p.grid_side <= VIEW_WALK_MAX_SIDE));
+  return false;
 }
 
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
@@ -1693,6 +1947,16 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
   }
   else if (mode != PB_MODE_721) {      // Integral_73Het, or Integral_73 when no grid is passed
     if (count) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_73HET>), dim3(waves), dim3(64), 0, s, p);
+    else if (pb_pipelined_eval(p, mode)) {
+      if (p.grid_z) hipLaunchKernelGGL(view_walk_kernel, dim3(p.tiles_x * p.tiles_y * p.ssaa * p.ssaa), dim3(64), 0, s, p);
+      if (p.xcd_run > 0) waves = (waves + 8 * p.xcd_run - 1) / (8 * p.xcd_run) * (8 * p.xcd_run);    // whole runs for every XCD
+      if (p.finalize_in_eval) {
+        hipLaunchKernelGGL(eval_items_het_kernel<true>, dim3(waves), dim3(64), 0, s, p);
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+      }
+      hipLaunchKernelGGL(eval_items_het_kernel<false>, dim3(waves), dim3(64), 0, s, p);
+    }
     else hipLaunchKernelGGL(eval_bins_queue_kernel<PB_MODE_73HET>, dim3(waves), dim3(64), 0, s, p);
   }
   else if (count && p.precise) hipLaunchKernelGGL((eval_bins_kernel<true, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);

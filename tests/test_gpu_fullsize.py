@@ -73,7 +73,10 @@ def test_full_size_heterogeneous_properties(pb):
         n_beams, n_segs = ctx.cast_photon_beams()
         segs = ctx.download_segments()
         lo, hi = ctx.root_box()
-        bins = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)
+        bins = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)       # default: relaxed arithmetic
+        ctx.set_precise(True)
+        exact = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)      # the reference's operation order
+        ctx.set_precise(False)
         parts = []
         for sel in (segs[0::2], segs[1::2]):
             ctx.upload_segments(sel, lo, hi)
@@ -87,10 +90,17 @@ def test_full_size_heterogeneous_properties(pb):
     ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
                                    segs, lo, hi, 8, 8, 16, 16, step_x=32, step_y=32, mode=orc.MODE_73HET,
                                    grid_sigma=sigma, side=side)
-    got = bins[8::32, 8::32][:16, :16]
     small = ref < 1000.0
-    err = np.abs(got - ref)[small]
+    err = np.abs(exact[8::32, 8::32][:16, :16] - ref)[small]
     assert (err <= 1e-5 * np.maximum(1.0, np.abs(ref[small]))).all(), err.max()
+    # relaxed arithmetic: the stated bar against the oracle on the lattice, and against the exact-order frame everywhere
+    ferr = np.abs(bins[8::32, 8::32][:16, :16] - ref)[small]
+    assert (ferr <= 2e-3 * np.maximum(1.0, np.abs(ref[small]))).all(), ferr.max()
+    both = ok & (exact < 1000.0)
+    d = np.abs(bins - exact)[both]
+    print(f"cfg3 relaxed vs exact order: max-abs {d.max():.3e} rmse {np.sqrt((d ** 2).mean()):.3e}")
+    assert (d <= 2e-3 * np.maximum(1.0, exact[both])).all(), d.max()
+    assert np.sqrt((d ** 2).mean()) <= 1e-4
 
 
 def test_largest_configuration_band(pb):
