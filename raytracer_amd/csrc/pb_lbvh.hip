@@ -6,8 +6,9 @@
 //      a device-wide exclusive scan of (digit, block) counts, and a stable
 //      scatter whose in-block ranks come from wave match masks and per-wave LDS
 //      counters (no atomics on the rank path, so the permutation is stable)
-//      (up to 64 sort blocks, 131 072 segments, every scatter block sums the block
-//      histograms itself: two launches per pass instead of five)
+//      (up to 64 sort blocks every scatter block sums the block histograms itself, and
+//      the histogram of a pass is counted by the launch before it - the key kernel, then
+//      each scatter for the next digit and the block a key lands in: one launch per pass)
 //   4. Karras (2012) hierarchy: one lane per internal node, ties between equal
 //      keys broken by sorted position
 //   5. node boxes from range tables: a node's box is the union of the leaf boxes
@@ -20,6 +21,7 @@
 // the device.
 // The reference's tree decides nothing about the result except through the gate
 // boxes stored with each segment; this structure only finds candidates.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -29,7 +31,8 @@
 namespace {
 
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 8;
+constexpr int SORT_ITEMS = 8;                     // keys per thread of a sort block ...
+constexpr int SORT_ITEMS_SMALL = 2;               // ... and for sets that would otherwise fill few blocks
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_PASSES = 6;    // 48 bits / 8
@@ -46,8 +49,11 @@ PB_HDI float ord_float(uint32_t o) {
   return f;
 }
 
-__global__ void bounds_init_kernel(uint32_t* __restrict__ bounds6) {
-  if (threadIdx.x < 6) bounds6[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+// Start values of the bounds, and zeros in the histograms that the key kernel and the scatter passes count into.
+__global__ __launch_bounds__(256) void build_init_kernel(uint32_t* __restrict__ bounds6, uint32_t* __restrict__ hist, int hist_words) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6) bounds6[i] = i < 3 ? 0xFFFFFFFFu : 0u;
+  for (int k = i; k < hist_words; k += gridDim.x * blockDim.x) hist[k] = 0u;
 }
 
 __global__ __launch_bounds__(256) void bounds_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
@@ -64,11 +70,18 @@ __global__ __launch_bounds__(256) void bounds_kernel(const float4* __restrict__ 
       lo[k] = fminf(lo[k], __shfl_down(lo[k], off, 64));
       hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off, 64));
     }
+  // one set of atomics per block: they all hit the same six words
+  __shared__ float red[6][4];
   if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 3; ++k) {
-      atomicMin(&bounds6[k], float_ord(lo[k]));
-      atomicMax(&bounds6[3 + k], float_ord(hi[k]));
-    }
+    for (int k = 0; k < 3; ++k) { red[k][threadIdx.x >> 6] = lo[k]; red[3 + k][threadIdx.x >> 6] = hi[k]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    float v = red[k][0];
+    for (int w = 1; w < 4; ++w) v = (k < 3) ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+    if (k < 3) atomicMin(&bounds6[k], float_ord(v));
+    else atomicMax(&bounds6[k], float_ord(v));
+  }
 }
 
 PB_HDI uint64_t expand16(uint32_t v) {   // bit k of v -> bit 3k
@@ -82,7 +95,8 @@ PB_HDI uint64_t expand16(uint32_t v) {   // bit k of v -> bit 3k
 
 __global__ __launch_bounds__(256) void morton_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
                                                     int n, const uint32_t* __restrict__ bounds6,
-                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                    uint32_t* __restrict__ hist0, int n_blocks, int tile) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 a = capA[i], b = capB[i];
@@ -96,19 +110,23 @@ __global__ __launch_bounds__(256) void morton_kernel(const float4* __restrict__ 
     t = fminf(fmaxf(t, 0.0f), 65535.0f);
     q[k] = (uint32_t)t;
   }
-  keys[i] = (expand16(q[0]) << 2) | (expand16(q[1]) << 1) | expand16(q[2]);
+  const uint64_t key = (expand16(q[0]) << 2) | (expand16(q[1]) << 1) | expand16(q[2]);
+  keys[i] = key;
   vals[i] = (uint32_t)i;
+  // the first sort pass' (digit, block) counts, where the scatter blocks sum them themselves
+  if (hist0) atomicAdd(&hist0[(size_t)((uint32_t)key & 255u) * n_blocks + i / tile], 1u);
 }
 
 // ---- radix sort ----
+template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t* __restrict__ keys, int n, int shift,
                                                                 int n_blocks, uint32_t* __restrict__ ghist) {
   __shared__ uint32_t hist[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  const int base = blockIdx.x * SORT_TILE;
+  const int base = blockIdx.x * SORT_THREADS * ITEMS;
 #pragma unroll
-  for (int k = 0; k < SORT_ITEMS; ++k) {
+  for (int k = 0; k < ITEMS; ++k) {
     const int i = base + k * SORT_THREADS + threadIdx.x;
     if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
   }
@@ -130,16 +148,30 @@ PB_DI unsigned long long match_digit(uint32_t digit, bool valid) {
 
 // SCANNED: gscan holds the device-wide exclusive scan of the (digit, block) counts.  Otherwise it holds the counts
 // themselves and every block sums what lies before its own (few blocks: cheaper than three scan launches per pass).
-template <bool SCANNED>
+// next_hist: where the next pass' (digit, block) counts are gathered as the keys are placed, or null.
+template <bool SCANNED, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in, int n,
                                                                    int shift, int n_blocks,
                                                                    const uint32_t* __restrict__ gscan,
                                                                    uint64_t* __restrict__ keys_out,
-                                                                   uint32_t* __restrict__ vals_out) {
+                                                                   uint32_t* __restrict__ vals_out,
+                                                                   uint32_t* __restrict__ next_hist) {
+  constexpr int TILE = SORT_THREADS * ITEMS;
   __shared__ uint32_t cnt[SORT_WAVES][256];
   __shared__ uint32_t goff[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wave w owns the contiguous keys [base + w*64*ITEMS, +64*ITEMS): order (wave, item, lane) = input order.
+  // They are requested first, so that their latency runs beside that of the histogram reads below.
+  const int wbase = blockIdx.x * TILE + wave * 64 * ITEMS;
+  uint64_t key[ITEMS];
+  uint32_t val[ITEMS], rank[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = wbase + k * 64 + lane;
+    key[k] = (i < n) ? keys_in[i] : 0ull;
+    val[k] = (i < n) ? vals_in[i] : 0u;
+  }
   for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
   if (SCANNED) {
     goff[threadIdx.x] = gscan[(size_t)threadIdx.x * n_blocks + blockIdx.x];
@@ -161,16 +193,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
     goff[threadIdx.x] = base + incl - total + before;
   }
   __syncthreads();
-  // wave w owns the contiguous keys [base + w*64*ITEMS, +64*ITEMS): order (wave, item, lane) = input order
-  const int wbase = blockIdx.x * SORT_TILE + wave * 64 * SORT_ITEMS;
-  uint64_t key[SORT_ITEMS];
-  uint32_t val[SORT_ITEMS], rank[SORT_ITEMS];
 #pragma unroll
-  for (int k = 0; k < SORT_ITEMS; ++k) {
+  for (int k = 0; k < ITEMS; ++k) {
     const int i = wbase + k * 64 + lane;
     const bool valid = i < n;
-    key[k] = valid ? keys_in[i] : 0ull;
-    val[k] = valid ? vals_in[i] : 0u;
     const uint32_t digit = (uint32_t)(key[k] >> shift) & 255u;
     const unsigned long long peers = match_digit(digit, valid);
     const unsigned long long below = peers & ((1ull << lane) - 1ull);
@@ -188,13 +214,14 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < SORT_ITEMS; ++k) {
+  for (int k = 0; k < ITEMS; ++k) {
     const int i = wbase + k * 64 + lane;
     if (i < n) {
       const uint32_t digit = (uint32_t)(key[k] >> shift) & 255u;
       const uint32_t dst = goff[digit] + cnt[wave][digit] + rank[k];
       keys_out[dst] = key[k];
       vals_out[dst] = val[k];
+      if (next_hist) atomicAdd(&next_hist[(size_t)((uint32_t)(key[k] >> (shift + 8)) & 255u) * n_blocks + dst / TILE], 1u);
     }
   }
 }
@@ -207,12 +234,34 @@ PB_DI int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
   return __builtin_clzll(x);
 }
 
+// capsule bounds with the slack the tile test uses
+PB_DI void capsule_box(float4 a, float4 b, float lo[3], float hi[3]) {
+  const float pad = a.w * 1.001f + 1e-5f;
+  lo[0] = fminf(a.x, b.x) - pad; lo[1] = fminf(a.y, b.y) - pad; lo[2] = fminf(a.z, b.z) - pad;
+  hi[0] = fmaxf(a.x, b.x) + pad; hi[1] = fmaxf(a.y, b.y) + pad; hi[2] = fmaxf(a.z, b.z) + pad;
+  // uploaded records may hold infinities or NaN: an infinite bound times a zero plane component is NaN in the
+  // tile test and would cull the whole subtree; keep every bound finite (a NaN record cannot contribute)
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = fmaxf(fminf(lo[k], 1e30f), -1e30f);
+    hi[k] = fmaxf(fminf(hi[k], 1e30f), -1e30f);
+  }
+}
+
 // Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees" (2012), alg. 4.
 // Children: >= 0 internal node, < 0 leaf ~child (sorted position).
+// Thread i also writes the box of leaf i (the capsule in sorted position i): one launch less.
 __global__ __launch_bounds__(256) void karras_kernel(const uint64_t* __restrict__ keys, int n, int* __restrict__ left,
                                                     int* __restrict__ right, int* __restrict__ range_lo,
-                                                    int* __restrict__ range_hi) {
+                                                    int* __restrict__ range_hi, const float4* __restrict__ capA,
+                                                    const float4* __restrict__ capB, const uint32_t* __restrict__ perm,
+                                                    float* __restrict__ leaf_box) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t sidx = perm[i];
+    float lo[3], hi[3];
+    capsule_box(capA[sidx], capB[sidx], lo, hi);
+    for (int k = 0; k < 3; ++k) { leaf_box[(size_t)i * 6 + k] = lo[k]; leaf_box[(size_t)i * 6 + 3 + k] = hi[k]; }
+  }
   if (i >= n - 1) return;
   const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
   const int dmin = delta(keys, n, i, i - d);
@@ -236,19 +285,6 @@ __global__ __launch_bounds__(256) void karras_kernel(const uint64_t* __restrict_
   range_lo[i] = lo; range_hi[i] = hi;      // the node spans the leaves lo..hi of the sorted order
 }
 
-// capsule bounds with the slack the tile test uses
-PB_DI void capsule_box(float4 a, float4 b, float lo[3], float hi[3]) {
-  const float pad = a.w * 1.001f + 1e-5f;
-  lo[0] = fminf(a.x, b.x) - pad; lo[1] = fminf(a.y, b.y) - pad; lo[2] = fminf(a.z, b.z) - pad;
-  hi[0] = fmaxf(a.x, b.x) + pad; hi[1] = fmaxf(a.y, b.y) + pad; hi[2] = fmaxf(a.z, b.z) + pad;
-  // uploaded records may hold infinities or NaN: an infinite bound times a zero plane component is NaN in the
-  // tile test and would cull the whole subtree; keep every bound finite (a NaN record cannot contribute)
-  for (int k = 0; k < 3; ++k) {
-    lo[k] = fmaxf(fminf(lo[k], 1e30f), -1e30f);
-    hi[k] = fmaxf(fminf(hi[k], 1e30f), -1e30f);
-  }
-}
-
 // Node boxes without a bottom-up walk.  A node's box is the union of the leaf boxes over its range of the
 // sorted order, and unions over aligned blocks of 64, 64^2, ... leaves are tabulated first, so a range is
 // covered by at most 126 table entries per level.  (The usual walk - each leaf climbs, the second arrival
@@ -259,16 +295,6 @@ struct RefitLevels {
   const float* box[REFIT_MAX_LEVELS];    // box[0] = leaf boxes, box[l] = unions of 64^l leaves
   int n_levels;
 };
-
-__global__ __launch_bounds__(256) void leaf_box_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
-                                                      const uint32_t* __restrict__ perm, int n, float* __restrict__ leaf_box) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t s = perm[i];
-  float lo[3], hi[3];
-  capsule_box(capA[s], capB[s], lo, hi);
-  for (int k = 0; k < 3; ++k) { leaf_box[(size_t)i * 6 + k] = lo[k]; leaf_box[(size_t)i * 6 + 3 + k] = hi[k]; }
-}
 
 // dst[b] = union of src[64 b .. 64 b + 63]: one wave per destination box.
 __global__ __launch_bounds__(256) void box_union64_kernel(const float* __restrict__ src, int n_src, float* __restrict__ dst) {
@@ -299,24 +325,24 @@ __global__ __launch_bounds__(256) void node_box_kernel(const RefitLevels lv, int
     long long size = 1;
     while (level + 1 < lv.n_levels && (i % (size * 64) == 0) && (i + size * 64 - 1 <= last)) { size *= 64; level++; }
     // Entries of this level from i on: up to the last one that lies inside the range, but not past the next
-    // multiple of 64 entries, where the level is chosen anew.  Four entries are requested before the first is
+    // multiple of 64 entries, where the level is chosen anew.  Eight entries are requested before the first is
     // used (an index past the run repeats its last entry, which changes no union): the loop waits for memory
-    // once per four entries, and that wait is what the kernel's time consists of.
+    // once per eight entries, and that wait is what the kernel's time consists of.
     const long long k0 = i / size;
     const long long k_fit = (last + 1) / size - 1;
     const long long k_end = (k0 | 63) < k_fit ? (k0 | 63) : k_fit;
     const float* base = lv.box[level];
-    for (long long k = k0; k <= k_end; k += 4) {
-      float v[4][6];
+    for (long long k = k0; k <= k_end; k += 8) {
+      float v[8][6];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const long long e = (k + u < k_end) ? k + u : k_end;
         const float* b = base + (size_t)e * 6;
 #pragma unroll
         for (int c = 0; c < 6; ++c) v[u][c] = b[c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
         for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[u][c]); hi[c] = fmaxf(hi[c], v[u][3 + c]); }
     }
     i = (k_end + 1) * size;
@@ -378,7 +404,7 @@ int pb_lbvh_build(pb_ctx* ctx) {
         sizeof(int) * C, sizeof(int) * C,              // left, right
         sizeof(float) * 6 * C, sizeof(float) * 6 * C,  // node_box, leaf_box
         sizeof(uint64_t) * C, sizeof(uint32_t) * C,    // scratch: keys2, vals2
-        sizeof(uint32_t) * hist_words,                 // (digit, block) histograms
+        sizeof(uint32_t) * std::max(hist_words, (size_t)SORT_PASSES * 256 * SORT_LOCAL_SUMS_MAX_BLOCKS),   // (digit, block) histograms
         sizeof(uint32_t) * (pb_scan_tmp_words((int)hist_words) + 8),   // scan scratch, total
         sizeof(int) * C, sizeof(int) * C,              // range_lo, range_hi
         sizeof(float) * C,                             // unions of 64, 64^2, ... leaf boxes: 6 (C/64 + C/4096 + ...) < 0.1 C floats
@@ -398,7 +424,11 @@ int pb_lbvh_build(pb_ctx* ctx) {
     ctx->lb_unions = (float*)take(sizes[15]); ctx->lb_bounds = (uint32_t*)take(sizes[16]);
     ctx->lb_cap = C;
   }
-  const int n_blocks = (n + SORT_TILE - 1) / SORT_TILE;
+  // Sets of up to 64 sort blocks (of 512 keys, else of 2048) need no separate histogram and scan launches.
+  const bool small = n <= SORT_LOCAL_SUMS_MAX_BLOCKS * SORT_THREADS * SORT_ITEMS_SMALL;
+  const int tile = small ? SORT_THREADS * SORT_ITEMS_SMALL : SORT_TILE;
+  const int n_blocks = (n + tile - 1) / tile;
+  const bool merged = n_blocks <= SORT_LOCAL_SUMS_MAX_BLOCKS;
   const size_t hist_words = (size_t)256 * n_blocks;
   uint64_t* keys2 = ctx->lb_keys2;
   uint32_t* vals2 = ctx->lb_vals2;
@@ -410,26 +440,35 @@ int pb_lbvh_build(pb_ctx* ctx) {
   float* unions = ctx->lb_unions;
   uint32_t* bounds = ctx->lb_bounds;
 
-  hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(64), 0, s, bounds);
-  int bblocks = (n + 255) / 256;
-  if (bblocks > 1024) bblocks = 1024;
+  {
+    const int zero_words = merged ? (int)(SORT_PASSES * hist_words) : 0;
+    hipLaunchKernelGGL(build_init_kernel, dim3(zero_words > 0 ? (zero_words + 1023) / 1024 : 1), dim3(256), 0, s, bounds, hist, zero_words);
+  }
+  int bblocks = (n + 1023) / 1024;      // few blocks: each ends in atomics on the same six words
+  if (bblocks > 256) bblocks = 256;
   hipLaunchKernelGGL(bounds_kernel, dim3(bblocks), dim3(256), 0, s, ctx->d_capA, ctx->d_capB, n, bounds);
   hipLaunchKernelGGL(morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->d_capA, ctx->d_capB, n, bounds,
-                     ctx->lb_keys, ctx->lb_perm);
+                     ctx->lb_keys, ctx->lb_perm, merged ? hist : nullptr, n_blocks, tile);
   PB_HIP(hipGetLastError());
   uint64_t* kin = ctx->lb_keys; uint32_t* vin = ctx->lb_perm;
   uint64_t* kout = keys2; uint32_t* vout = vals2;
   for (int pass = 0; pass < SORT_PASSES; ++pass) {
     const int shift = 8 * pass;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, n, shift, n_blocks, hist);
-    if (n_blocks <= SORT_LOCAL_SUMS_MAX_BLOCKS) {
-      hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift, n_blocks, hist,
-                         kout, vout);
+    if (merged) {
+      uint32_t* mine = hist + (size_t)pass * hist_words;
+      uint32_t* next = pass + 1 < SORT_PASSES ? mine + hist_words : nullptr;
+      if (small)
+        hipLaunchKernelGGL((sort_scatter_kernel<false, SORT_ITEMS_SMALL>), dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift,
+                           n_blocks, mine, kout, vout, next);
+      else
+        hipLaunchKernelGGL((sort_scatter_kernel<false, SORT_ITEMS>), dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift,
+                           n_blocks, mine, kout, vout, next);
     } else {
+      hipLaunchKernelGGL(sort_hist_kernel<SORT_ITEMS>, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, n, shift, n_blocks, hist);
       int rc = pb_exclusive_scan_u32(hist, hist, (int)hist_words, total, scan_tmp, s);
       if (rc != PB_OK) return rc;
-      hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift, n_blocks, hist,
-                         kout, vout);
+      hipLaunchKernelGGL((sort_scatter_kernel<true, SORT_ITEMS>), dim3(n_blocks), dim3(SORT_THREADS), 0, s, kin, vin, n, shift, n_blocks,
+                         hist, kout, vout, (uint32_t*)nullptr);
     }
     PB_HIP(hipGetLastError());
     uint64_t* tk = kin; kin = kout; kout = tk;
@@ -437,10 +476,8 @@ int pb_lbvh_build(pb_ctx* ctx) {
   }
   // SORT_PASSES is even: the sorted data is back in lb_keys / lb_perm
   static_assert(SORT_PASSES % 2 == 0, "sorted keys must end in the persistent buffers");
-  hipLaunchKernelGGL(karras_kernel, dim3((n - 1 + 255) / 256), dim3(256), 0, s, ctx->lb_keys, n, ctx->lb_left,
-                     ctx->lb_right, range_lo, range_hi);
-  hipLaunchKernelGGL(leaf_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->d_capA, ctx->d_capB, ctx->lb_perm, n,
-                     ctx->lb_leaf_box);
+  hipLaunchKernelGGL(karras_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->lb_keys, n, ctx->lb_left,
+                     ctx->lb_right, range_lo, range_hi, ctx->d_capA, ctx->d_capB, ctx->lb_perm, ctx->lb_leaf_box);
   RefitLevels lv;
   lv.box[0] = ctx->lb_leaf_box; lv.n_levels = 1;
   {
