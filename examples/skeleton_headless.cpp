@@ -16,6 +16,7 @@
 using namespace pbhost;
 
 int main(int argc, char** argv) {
+  try { UseDevicesFromEnvironment(); } catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
   if (argc > 1 && std::strcmp(argv[1], "analysis") == 0) {
     try { RunAnalysis(); Shutdown(); } catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
     return 0;

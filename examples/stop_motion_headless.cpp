@@ -19,6 +19,7 @@ static void surface(const mat4& matrix, double time) {
 }
 
 int main(int argc, char** argv) {
+  try { UseDevicesFromEnvironment(); } catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
   if (argc > 1) control.photon_number = std::atoi(argv[1]);
   if (argc > 2) control.screen_width = control.screen_height = std::atoi(argv[2]);
   const int begin = argc > 3 ? std::atoi(argv[3]) : 16, finish = argc > 4 ? std::atoi(argv[4]) : 24;

@@ -3,10 +3,12 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 namespace pbhost {
 
@@ -19,6 +21,7 @@ vec4 camera{0, 0, -3, 1.0f};
 vec3 theta{0.0f, 0.0f, 0.0f};
 Grid GRID;
 pb_control control = [] { pb_control c; pb_control_defaults(&c); return c; }();
+std::vector<int> devices{0};
 
 namespace {
 
@@ -43,15 +46,105 @@ pb_control current_control() {
   return c;
 }
 
+// Contexts of devices[1..]: they only render.  What they need - scene, grid, rendered segment set - is kept on the
+// host and uploaded when it changes (g_*_version against the versions a helper has seen).
+struct Helper { pb_ctx* ctx = nullptr; int device = 0; unsigned scene_seen = 0, segs_seen = 0; };
+std::vector<Helper> g_helpers;
+std::vector<float> g_tri_flat;          // 9 floats per triangle, as pb_set_scene takes them
+float g_matrix[16];
+std::vector<pb_segment> g_render_segs;  // the rendered set (BuildTree / LoadSegments) and its root box
+float g_render_lo[3], g_render_hi[3];
+unsigned g_scene_version = 0, g_segs_version = 0;
+
+void drop_helpers() {
+  for (Helper& h : g_helpers) if (h.ctx) pb_destroy(h.ctx);
+  g_helpers.clear();
+}
+
 pb_ctx* context() {
-  if (!g_ctx) check(pb_create(&control, 0, &g_ctx), "pb_create");
+  if (devices.empty()) devices.push_back(0);
+  if (!g_ctx) check(pb_create(&control, devices[0], &g_ctx), "pb_create");
   return g_ctx;
+}
+
+void upload_grid(pb_ctx* ctx, const Grid& grid);
+
+// The helper contexts, one per entry of devices[1..], brought up to date with scene, grid and segment set.
+std::vector<Helper>& helpers() {
+  bool same = g_helpers.size() + 1 == devices.size();
+  for (size_t i = 0; same && i < g_helpers.size(); ++i) same = g_helpers[i].device == devices[i + 1];
+  if (!same) {
+    drop_helpers();
+    for (size_t i = 1; i < devices.size(); ++i) {
+      Helper h;
+      h.device = devices[i];
+      check(pb_create(&control, h.device, &h.ctx), "pb_create (helper device)");
+      g_helpers.push_back(h);
+    }
+  }
+  for (Helper& h : g_helpers) {
+    if (h.scene_seen != g_scene_version) {
+      check(pb_set_scene(h.ctx, g_tri_flat.data(), (int)(g_tri_flat.size() / 9), g_matrix), "pb_set_scene (helper device)");
+      if (control.heterogeneous) upload_grid(h.ctx, GRID);
+      h.scene_seen = g_scene_version;
+    }
+    if (h.segs_seen != g_segs_version) {
+      if (control.heterogeneous) upload_grid(h.ctx, GRID);      // stop motion: a new field comes with a new set
+      check(pb_upload_segments(h.ctx, g_render_segs.data(), (int)g_render_segs.size(), g_render_lo, g_render_hi),
+            "pb_upload_segments (helper device)");
+      h.segs_seen = g_segs_version;
+    }
+  }
+  return g_helpers;
+}
+
+void remember_scene(const std::vector<float>& tri, const mat4& matrix) {
+  g_tri_flat = tri;
+  std::memcpy(g_matrix, &matrix.m[0][0], sizeof(g_matrix));
+  g_scene_version++;
+}
+
+void remember_render_set(const pb_segment* segs, size_t n, const float lo[3], const float hi[3]) {
+  g_render_segs.assign(segs, segs + n);
+  for (int k = 0; k < 3; ++k) { g_render_lo[k] = lo[k]; g_render_hi[k] = hi[k]; }
+  g_segs_version++;
+}
+
+// One frame into scr->buffer: on one device a single call; on several, bands of 64 rows dealt round robin (the lit
+// cone makes rows cost very differently), one host thread per device, each writing its rows of the host image.
+void render_frame(screen* scr, int mode) {
+  pb_ctx* ctx = context();
+  const int w = scr->width, h = scr->height;
+  std::vector<float> rgb((size_t)w * h * 3);
+  if (devices.size() <= 1) {
+    check(pb_render(ctx, 0, 0, w, h, mode, /*screen bins*/ 2, rgb.data()), "pb_render");
+  } else {
+    std::vector<Helper>& hs = helpers();
+    std::vector<pb_ctx*> all{ctx};
+    for (Helper& x : hs) all.push_back(x.ctx);
+    const int n_dev = (int)all.size(), band = 64, n_bands = (h + band - 1) / band;
+    std::vector<std::string> errors((size_t)n_dev);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < n_dev; ++d)
+      workers.emplace_back([&, d] {
+        for (int b = d; b < n_bands; b += n_dev) {
+          const int y0 = b * band, hb = (y0 + band <= h) ? band : h - y0;
+          if (pb_render(all[(size_t)d], 0, y0, w, hb, mode, 2, rgb.data() + (size_t)y0 * w * 3) != PB_OK) {
+            errors[(size_t)d] = pb_last_error();     // the error text is per thread: take it here
+            return;
+          }
+        }
+      });
+    for (std::thread& t : workers) t.join();
+    for (const std::string& e : errors) if (!e.empty()) throw std::runtime_error("pb_render: " + e);
+  }
+  check(pb_quantise_argb(rgb.data(), w * h, scr->buffer), "pb_quantise_argb");
 }
 
 void recreate_context_if_control_changed() {
   static pb_control last = control;
   pb_control now = current_control();
-  if (g_ctx && std::memcmp(&last, &now, sizeof(now)) != 0) { pb_destroy(g_ctx); g_ctx = nullptr; }
+  if (g_ctx && std::memcmp(&last, &now, sizeof(now)) != 0) { pb_destroy(g_ctx); g_ctx = nullptr; drop_helpers(); }
   control = now;
   last = now;
 }
@@ -104,6 +197,7 @@ AABB CastPhotonBeams(int number, std::vector<PhotonBeam>& beams_const, std::vect
   }
   g_triangles = triangles;
   check(pb_set_scene(ctx, tri.data(), (int)triangles.size(), &matrix.m[0][0]), "pb_set_scene");
+  remember_scene(tri, matrix);
   if (control.heterogeneous) upload_grid(ctx, GRID);
   int n_beams = 0, n_segs = 0;
   check(pb_emit_beams(ctx, number, control.seed, &n_beams, &n_segs), "pb_emit_beams");
@@ -225,6 +319,7 @@ void BuildTree(Node* parent, std::vector<PhotonSeg>& child, int) {
   const float lo[3] = {r.min.x, r.min.y, r.max.z}, hi[3] = {r.max.x, r.max.y, r.min.z};
   check(pb_upload_segments(ctx, segs.data(), (int)segs.size(), lo, hi), "pb_upload_segments");
   check(pb_build_lbvh(ctx), "pb_build_lbvh");
+  remember_render_set(segs.data(), segs.size(), lo, hi);
   parent->leaf = child.size() <= 2;
 }
 
@@ -293,20 +388,10 @@ void KillSDL(screen* s) {
   delete s;
 }
 
-void DrawStandard(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>) {
-  pb_ctx* ctx = context();
-  std::vector<float> rgb((size_t)scr->width * scr->height * 3);
-  check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_721, /*screen bins*/ 2, rgb.data()), "pb_render");
-  check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
-}
+void DrawStandard(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>) { render_frame(scr, PB_MODE_721); }
 
-void Draw(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, std::vector<PhotonSeg>&) {
-  pb_ctx* ctx = context();
-  // BeamRadiance's per-segment dispatch (BeamRadiance.h:486-543): cones if ADAPTIVE, else by ONE_DIMENSIONAL
-  std::vector<float> rgb((size_t)scr->width * scr->height * 3);
-  check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_DEFAULT, /*screen bins*/ 2, rgb.data()), "pb_render");
-  check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
-}
+// BeamRadiance's per-segment dispatch (BeamRadiance.h:486-543): cones if ADAPTIVE, else by ONE_DIMENSIONAL
+void Draw(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, std::vector<PhotonSeg>&) { render_frame(scr, PB_MODE_DEFAULT); }
 
 void RunAnalysis() {
   pb_ctx* ctx = context();
@@ -335,12 +420,7 @@ void RunAnalysis() {
   }
 }
 
-void DrawHet(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, NodeGen*) {
-  pb_ctx* ctx = context();
-  std::vector<float> rgb((size_t)scr->width * scr->height * 3);
-  check(pb_render(ctx, 0, 0, scr->width, scr->height, PB_MODE_73HET, /*screen bins*/ 2, rgb.data()), "pb_render");
-  check(pb_quantise_argb(rgb.data(), scr->width * scr->height, scr->buffer), "pb_quantise_argb");
-}
+void DrawHet(screen* scr, std::vector<PhotonBeam>, std::vector<PhotonBeam>, NodeGen*) { render_frame(scr, PB_MODE_73HET); }
 
 void LoadSegments(const char* path, const mat4& matrix, const std::vector<Triangle>& triangles) {
   extinction_c = absorption_c + scattering_c;
@@ -353,7 +433,17 @@ void LoadSegments(const char* path, const mat4& matrix, const std::vector<Triang
   }
   g_triangles = triangles;
   check(pb_set_scene(ctx, tri.data(), (int)triangles.size(), &matrix.m[0][0]), "pb_set_scene");
+  remember_scene(tri, matrix);
   check(pb_load_segments(ctx, path), "pb_load_segments");
+  if (devices.size() > 1) {      // the other devices get the set from the host
+    int n = 0, got = 0;
+    check(pb_segment_count(ctx, &n), "pb_segment_count");
+    std::vector<pb_segment> segs((size_t)(n > 0 ? n : 1));
+    check(pb_download_segments(ctx, segs.data(), (int)segs.size(), &got), "pb_download_segments");
+    float lo[3], hi[3];
+    check(pb_get_root_box(ctx, lo, hi), "pb_get_root_box");
+    remember_render_set(segs.data(), (size_t)got, lo, hi);
+  }
 }
 void SaveSegments(const char* path) { check(pb_save_segments(context(), path), "pb_save_segments"); }
 
@@ -363,7 +453,23 @@ pb_stats Stats() {
   return s;
 }
 
+void UseDevicesFromEnvironment() {
+  const char* e = std::getenv("PB_DEVICES");
+  if (!e || !*e) return;
+  std::vector<int> list;
+  for (const char* p = e; *p;) {
+    char* end = nullptr;
+    const long v = std::strtol(p, &end, 10);
+    if (end == p || v < 0) throw std::runtime_error(std::string("PB_DEVICES: not a list of device indices: ") + e);
+    list.push_back((int)v);
+    p = (*end == ',') ? end + 1 : end;
+    if (*end && *end != ',') throw std::runtime_error(std::string("PB_DEVICES: not a list of device indices: ") + e);
+  }
+  if (!list.empty()) devices = list;
+}
+
 void Shutdown() {
+  drop_helpers();
   if (g_ctx) { pb_destroy(g_ctx); g_ctx = nullptr; }
 }
 

@@ -35,6 +35,12 @@ extern vec4 camera;
 extern vec3 theta;
 // Control.h:4-31 — compile-time switches there, run-time values here (same names, lower case).
 extern pb_control control;
+// GPUs a frame is spread over (HIP device indices; default {0}; skeleton_headless reads PB_DEVICES="0,1,...").  The
+// photon pass runs on the first; every device holds the scene, the grid and the rendered segment set, and
+// DrawStandard / DrawHet / Draw give the frame's rows to the devices in bands of 64, round robin, one host thread
+// per device.  The image does not depend on the list (a device may be named twice).
+extern std::vector<int> devices;
+void UseDevicesFromEnvironment();   // devices = the list in PB_DEVICES, if that is set
 
 struct Triangle {                 // TestModelH.h:12-39
   vec4 v0, v1, v2, normal;
