@@ -164,8 +164,13 @@ class Bench:
             sys.exit(3)
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
-        if self.world > 1:
+        # --rehearse-exchange: a job of one rank goes through everything a job of several does (RCCL process group,
+        # segment broadcast, pipelined strip gather on the collective's stream, watchdog), so that code has run on
+        # the hardware before a node with several GPUs sees it
+        self.exchange = self.world > 1 or args.rehearse_exchange
+        if self.exchange:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
             self.watchdog()
             # a collective that never completes ends the job after STALL_SECONDS with RCCL's own report
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev,
@@ -174,11 +179,11 @@ class Bench:
     def watchdog(self, _i=None):
         """(Re-)armed after every step: STALL_SECONDS without one ends the process with every thread's stack on
         stderr and exit status 1, instead of holding the whole job in a collective."""
-        if self.world > 1:
+        if self.exchange:
             faulthandler.dump_traceback_later(STALL_SECONDS, exit=True)
 
     def close(self):
-        if self.world > 1:
+        if self.exchange:
             self.dist.barrier()
             self.dist.destroy_process_group()
             faulthandler.cancel_dump_traceback_later()
@@ -209,13 +214,13 @@ class Bench:
             n_beams, n_segs = ctx.cast_photon_beams()
             segs = ctx.download_segments()
             root = np.concatenate(ctx.root_box()).astype(np.float32)
-        if world > 1:
+        if self.exchange:
             buf, n_segs, root = tiles.broadcast_segments(segs, root, dev, itemsize=pb.SEGMENT_DTYPE.itemsize)   # RCCL broadcast
             nb = torch.tensor([n_beams if rank == 0 else 0], device=dev)
             dist.broadcast(nb, 0)
             n_beams = int(nb.item())
             torch.cuda.synchronize()
-            if rank != 0:
+            if rank != 0 or args.rehearse_exchange:     # the rehearsal renders from the broadcast records, as ranks > 0 do
                 ctx.upload_segments_device(buf.data_ptr(), n_segs, root[:3], root[3:],
                                            stream=torch.cuda.current_stream().cuda_stream)
                 torch.cuda.synchronize()
@@ -228,7 +233,7 @@ class Bench:
         # ---- strips of this rank ----
         first_strip, strip_stride, n_my = tiles.strips_of_rank(H, rank, world)
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-        pipe = tiles.StripPipeline(world, n_my * 8, W, dev, frame=frame, timeout_s=STALL_SECONDS)
+        pipe = tiles.StripPipeline(world, n_my * 8, W, dev, frame=frame, timeout_s=STALL_SECONDS, exchange=self.exchange)
         stream = torch.cuda.current_stream().cuda_stream
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -237,7 +242,7 @@ class Bench:
 
         tiles.run_steps(pipe, frame, render, warmup, on_step=self.watchdog)
         torch.cuda.synchronize()
-        if world > 1:
+        if self.exchange:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -247,17 +252,17 @@ class Bench:
         tiles.run_steps(pipe, frame, render, steps, on_step=self.watchdog)   # every frame gathered and assembled in here
         ev1.record()
         torch.cuda.synchronize()
-        if world > 1:
+        if self.exchange:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if self.exchange:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         kernel_ms = ev0.elapsed_time(ev1) / steps
         kt = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-        if world > 1:
+        if self.exchange:
             dist.all_reduce(kt, op=dist.ReduceOp.MAX)
         kernel_ms = float(kt.item())
         self.watchdog()
@@ -287,7 +292,8 @@ class Bench:
                                        f"{'heterogeneous' if het else 'homogeneous'} medium, SEED 42 (GPU photon pass: "
                                        f"{n_beams} beams, {n_segs} segments, own-box gate rule)",
                            "rays_per_frame": rays, "segments": n_segs, "cull": cull,
-                           "parallelism": f"row-strips x{world}" if world > 1 else "single GPU"},
+                           "parallelism": f"row-strips x{world}" if world > 1 else
+                                          ("single GPU, strips exchanged over RCCL as with several" if self.exchange else "single GPU")},
                 "roofline": {
                     "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_TFLOPS,
@@ -342,6 +348,9 @@ def main():
                     help="how a tile finds its candidate segments (default: screen-space bins)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only", action="store_true", help="measure --workload alone (no `other_workloads`)")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="one rank, but through the RCCL process group, the segment broadcast and the pipelined strip "
+                         "gather of a job of several (a check of that code on one GPU; not the headline measurement)")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="frames kept in flight for the extra `pipelined` figure (0: skip it); `value` itself is always "
                          "measured one frame after the other on one stream")

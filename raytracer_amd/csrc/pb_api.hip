@@ -233,7 +233,17 @@ int ensure_blk(FrameWorkspace& ws, size_t need) {
 }
 
 // Frame through screen-space bins (cull mode 2); p is complete except for the workspace pointers.
-int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, const unsigned long long key[6], hipStream_t s) {
+int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, const unsigned long long key_in[6], hipStream_t s) {
+  // Lane-per-macro-tile binning tests every segment against every macro tile and keeps a counter per (block of 128
+  // segments, macro tile), which one block sums: the right trade for the segment sets a frame usually has, not
+  // for millions of segments (23.7 M segments, a 4096 x 128 band: 85 ms a frame against 11 ms for the walk over
+  // each segment's own rectangle of macro tiles).  The two ways fill the lists by different (conservative) tests, so
+  // what was sized for one says nothing about the other: the limit is part of the key.
+  int fused_max_seg = 1 << 20;
+  if (const char* e = std::getenv("PB_TUNE_FUSED_MAX")) { int v = std::atoi(e); if (v >= 0) fused_max_seg = v; }
+  unsigned long long key[6];
+  std::memcpy(key, key_in, sizeof(key));
+  key[4] |= ((unsigned long long)(uint32_t)fused_max_seg + 1ull) << 8;
   const int tiles = p.tiles_x * p.tiles_y;
   const int groups = tiles * p.ssaa * p.ssaa;
   const size_t px = (size_t)tiles * 64;      // pixel sums are stored per tile
@@ -283,7 +293,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     p.bin_list = ws.d_bin_list; p.items = ws.d_items; p.accum = ws.d_accum;
     p.tile_items = p.tile_done = nullptr; p.finalize_in_eval = 0;
     p.bin_capacity = ws.ws_bin_cap; p.item_capacity = ws.ws_item_cap;
-    p.fused_queue = (mtiles <= pb_fused_queue_macros()) ? 1 : 0;
+    p.fused_queue = (mtiles <= pb_fused_queue_macros() && p.n_seg <= fused_max_seg) ? 1 : 0;
     // frames whose queue one block builds bin without atomics: the counters' space holds the per-tile item counts
     if (p.fused_queue) { p.tile_items = p.sub_count; p.tile_done = p.sub_fill; }
     p.bin_mask = nullptr;

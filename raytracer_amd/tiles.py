@@ -73,19 +73,22 @@ class StripPipeline:
         pipe.drain(frame)
     """
 
-    def __init__(self, world, rows, width, device, channels=3, depth=2, frame=None, timeout_s=120.0):
+    def __init__(self, world, rows, width, device, channels=3, depth=2, frame=None, timeout_s=120.0, exchange=False):
+        """exchange=True runs the collective path even in a job of one rank (a rehearsal of the N > 1 code on one
+        GPU: the gather then has one participant, everything else is as with several)."""
         self.world = world
         self.timeout_s = timeout_s
-        backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else None
+        self.collective = world > 1 or (exchange and dist.is_initialized())
+        backend = dist.get_backend() if (self.collective and dist.is_initialized()) else None
         self.overlapped = backend == "nccl"
-        self.depth = depth if (world == 1 or self.overlapped) else 1
+        self.depth = depth if (not self.collective or self.overlapped) else 1
         # one rank owns every strip: it renders straight into the frame, nothing to exchange or copy
-        self.direct = world == 1 and frame is not None and tuple(frame.shape) == (rows, width, channels)
+        self.direct = not self.collective and frame is not None and tuple(frame.shape) == (rows, width, channels)
         self.mine = [frame if self.direct else torch.zeros((rows, width, channels), dtype=torch.float32, device=device)
                      for _ in range(self.depth)]
         self.gathered = [torch.zeros((world, rows, width, channels), dtype=torch.float32, device=device)
-                         if world > 1 else None for _ in range(self.depth)]
-        self.staged = world > 1 and not self.overlapped
+                         if self.collective else None for _ in range(self.depth)]
+        self.staged = self.collective and not self.overlapped
         if self.staged:
             self.h_mine = torch.zeros((rows, width, channels), dtype=torch.float32)
             self.h_gathered = torch.zeros((world * rows, width, channels), dtype=torch.float32)
@@ -96,7 +99,7 @@ class StripPipeline:
     def _finish(self, slot, frame):
         if not self.filled[slot]:
             return
-        if self.world == 1:
+        if not self.collective:
             if not self.direct:
                 frame.copy_(self.mine[slot])
         else:
@@ -112,7 +115,7 @@ class StripPipeline:
         return slot
 
     def submit(self, slot):
-        if self.world > 1:
+        if self.collective:
             g = self.gathered[slot]
             if self.overlapped:
                 self.work[slot] = dist.all_gather_into_tensor(g.view(-1, *g.shape[2:]), self.mine[slot], async_op=True)

@@ -434,3 +434,33 @@ def test_repeated_frames_of_one_segment_set_are_bit_identical(pb, kw):
         assert np.array_equal(part, first[24:24 + 77, 40:40 + 99])
         assert np.array_equal(ctx.draw(cull="bins"), first)
         assert np.array_equal(ctx.draw(cull="bins"), first)
+
+
+@pytest.mark.parametrize("het", [False, True])
+def test_both_binning_passes_give_the_same_frame(pb, het, monkeypatch):
+    """Segment sets above a limit (2^20) are binned by the walk over each segment's own rectangle of macro tiles and
+    the multi-kernel queue, smaller ones by the lane-per-macro-tile pass: lowered to 0, the limit sends a small set
+    down the first way.  The sums are fixed point, so the frames must agree bit for bit."""
+    import os
+    kw = dict(photon_number=1500, bounces=2, screen_width=256, screen_height=256)
+    if het:
+        kw.update(heterogeneous=1, one_dimensional=1)
+    mode = pb.MODE_73HET if het else pb.MODE_721
+    frames = {}
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene()
+        if het:
+            ctx.set_grid(*pb.make_grid())
+            ctx.set_precise(True)          # the exact-order estimator runs behind either pass
+        ctx.cast_photon_beams()
+        for limit in ("", "0", ""):
+            if limit:
+                monkeypatch.setenv("PB_TUNE_FUSED_MAX", limit)
+            else:
+                monkeypatch.delenv("PB_TUNE_FUSED_MAX", raising=False)
+            assert os.environ.get("PB_TUNE_FUSED_MAX", "") == limit
+            frames.setdefault(limit, []).extend(ctx.draw(mode=mode, cull="bins") for _ in range(2))
+    ref = frames[""][0]
+    assert ref.max() > 0.05 and np.isfinite(ref).all()
+    for f in frames[""][1:] + frames["0"]:
+        assert np.array_equal(f, ref)
