@@ -1446,6 +1446,11 @@ PB_DI void smem_load8(u32x8& dst, const HetFast* base, uint32_t byte_offset) {
   asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(dst) : "s"(base), "s"(byte_offset));
 }
 PB_DI void smem_wait(u32x16& a, u32x16& b, u32x8& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c)); }
+// The same loads from a record's own 64-bit address (first or second half): segment sets whose records span more than
+// the 2 GB a 32-bit byte offset is trusted with (11 M segments) cannot be indexed from the array's base.
+PB_DI void smem_load16_first(u32x16& dst, const SegFrame* rec) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(dst) : "s"(rec)); }
+PB_DI void smem_load16_second(u32x16& dst, const SegFrame* rec) { asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=&s"(dst) : "s"(rec)); }
+PB_DI void smem_load8_at(u32x8& dst, const HetFast* rec) { asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(dst) : "s"(rec)); }
 
 struct HetItem {
   const SegFrame* frames;
@@ -1462,14 +1467,21 @@ struct HetItem {
 
 // Returns the lanes whose pair the exact-order code has to decide (pair_het_fast_geometry; likewise an axis point
 // within HET_FAST_EDGE of an end of the segment's stretch of the beam).
+template <bool WIDE>
 PB_DI unsigned long long pair_step_het(const HetItem& h, u32x16& cur, u32x16& nxt, uint32_t idx_cur, uint32_t idx_nxt, const Ray& r,
                                        PairSums& sum) {
-  const uint32_t off_cur = idx_cur * (uint32_t)sizeof(SegFrame), off_nxt = idx_nxt * (uint32_t)sizeof(SegFrame);
   u32x16 second;
   u32x8 third;
-  smem_load16(second, h.frames, off_cur + 64u);
-  smem_load8(third, h.het, idx_cur * (uint32_t)sizeof(HetFast));
-  smem_load16(nxt, h.frames, off_nxt);
+  if (WIDE) {
+    smem_load16_second(second, h.frames + idx_cur);
+    smem_load8_at(third, h.het + idx_cur);
+    smem_load16_first(nxt, h.frames + idx_nxt);
+  } else {
+    const uint32_t off_cur = idx_cur * (uint32_t)sizeof(SegFrame), off_nxt = idx_nxt * (uint32_t)sizeof(SegFrame);
+    smem_load16(second, h.frames, off_cur + 64u);
+    smem_load8(third, h.het, idx_cur * (uint32_t)sizeof(HetFast));
+    smem_load16(nxt, h.frames, off_nxt);
+  }
   SegHalfA a;
   __builtin_memcpy(&a, &cur, 64);
   float tc_minus = 0.0f, t_mid = 0.0f, y_star = 0.0f, y_err = 0.0f, sin2 = 1.0f;
@@ -1530,7 +1542,7 @@ __global__ __launch_bounds__(64) void view_walk_kernel(const RenderParams p) {
   view_walk_store(w, wt + VIEW_WALK_ROWS * 64, lane);
 }
 
-template <bool FINALIZE>
+template <bool FINALIZE, bool WIDE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void eval_items_het_kernel(const RenderParams p) {
   __shared__ uint32_t surv[PB_SLICE];
   __shared__ float tab[VIEW_WALK_ROWS * 64];
@@ -1640,21 +1652,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const int mine = (lane < nb) ? (int)surv[b0 + lane] : 0;
     uint32_t idx_cur = (uint32_t)__builtin_amdgcn_readlane(mine, 0);
     u32x16 ra, rb;
-    smem_load16(ra, h.frames, idx_cur * (uint32_t)sizeof(SegFrame));
+    if (WIDE) smem_load16_first(ra, h.frames + idx_cur);
+    else smem_load16(ra, h.frames, idx_cur * (uint32_t)sizeof(SegFrame));
     smem_wait(ra);
     int k = 0;
     for (; k + 1 < nb; k += 2) {
       const uint32_t idx1 = (uint32_t)__builtin_amdgcn_readlane(mine, k + 1);
       const int k2 = (k + 2 < nb) ? k + 2 : nb - 1;
       const uint32_t idx2 = (uint32_t)__builtin_amdgcn_readlane(mine, k2);
-      const unsigned long long m0 = pair_step_het(h, ra, rb, idx_cur, idx1, r, sum);
+      const unsigned long long m0 = pair_step_het<WIDE>(h, ra, rb, idx_cur, idx1, r, sum);
       if (m0) { push(m0, idx_cur); if (pending >= 64) drain(64); }
-      const unsigned long long m1 = pair_step_het(h, rb, ra, idx1, idx2, r, sum);
+      const unsigned long long m1 = pair_step_het<WIDE>(h, rb, ra, idx1, idx2, r, sum);
       if (m1) { push(m1, idx1); if (pending >= 64) drain(64); }
       idx_cur = idx2;
     }
     if (k < nb) {
-      const unsigned long long m = pair_step_het(h, ra, rb, idx_cur, idx_cur, r, sum);
+      const unsigned long long m = pair_step_het<WIDE>(h, ra, rb, idx_cur, idx_cur, r, sum);
       if (m) { push(m, idx_cur); if (pending >= 64) drain(64); }
     }
   }
@@ -1835,9 +1848,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
 int pb_fused_queue_macros(void) { return QUEUE_FUSED_MACROS; }
 
 // Whether an uncounted frame of `mode` is evaluated by eval_items_fast_kernel (one wave per item, 32-bit record offsets).
+static bool wide_records(const RenderParams& p) { return (size_t)p.n_seg * sizeof(SegFrame) >= ((size_t)1 << 31); }
 bool pb_pipelined_eval(const RenderParams& p, int mode) {
-  if (p.precise || p.eval_waves > 0 || (size_t)p.n_seg * sizeof(SegFrame) >= ((size_t)1 << 31) || std::getenv("PB_OLD_EVAL")) return false;
-  if (mode == PB_MODE_721) return true;
+  if (p.precise || p.eval_waves > 0 || std::getenv("PB_OLD_EVAL")) return false;
+  if (mode == PB_MODE_721) return !wide_records(p);
+  // eval_items_het_kernel addresses records beyond 2 GB by their own 64-bit addresses (its WIDE form)
   // eval_items_het_kernel: its walk tables hold the crossings of a grid of at most VIEW_WALK_MAX_SIDE points a side
   if (mode == PB_MODE_73 || mode == PB_MODE_73HET)
     return p.het_fast && (!p.grid_z || (p.walk && p.grid_side >= 2 && p.grid_side <= VIEW_WALK_MAX_SIDE));
@@ -1950,12 +1965,15 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
     else if (pb_pipelined_eval(p, mode)) {
       if (p.grid_z) hipLaunchKernelGGL(view_walk_kernel, dim3(p.tiles_x * p.tiles_y * p.ssaa * p.ssaa), dim3(64), 0, s, p);
       if (p.xcd_run > 0) waves = (waves + 8 * p.xcd_run - 1) / (8 * p.xcd_run) * (8 * p.xcd_run);    // whole runs for every XCD
+      const bool wide = wide_records(p) || std::getenv("PB_TUNE_WIDE") != nullptr;
       if (p.finalize_in_eval) {
-        hipLaunchKernelGGL(eval_items_het_kernel<true>, dim3(waves), dim3(64), 0, s, p);
+        if (wide) hipLaunchKernelGGL((eval_items_het_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((eval_items_het_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
         PB_HIP(hipGetLastError());
         return PB_OK;
       }
-      hipLaunchKernelGGL(eval_items_het_kernel<false>, dim3(waves), dim3(64), 0, s, p);
+      if (wide) hipLaunchKernelGGL((eval_items_het_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
+      else hipLaunchKernelGGL((eval_items_het_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
     }
     else hipLaunchKernelGGL(eval_bins_queue_kernel<PB_MODE_73HET>, dim3(waves), dim3(64), 0, s, p);
   }

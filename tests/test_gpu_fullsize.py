@@ -116,6 +116,8 @@ def test_largest_configuration_band(pb):
         n_beams, n_segs = ctx.cast_photon_beams()
         whole = ctx.draw(0, y0, S, band, mode=pb.MODE_73HET, cull="bins")
         halves = [ctx.draw(0, y0 + i * 64, S, 64, mode=pb.MODE_73HET, cull="bins") for i in range(2)]
+        ctx.set_precise(True)                              # the reference's operation order (one grid walk per valid pair)
+        exact = ctx.draw(0, y0, S, band, mode=pb.MODE_73HET, cull="bins")
         segs = ctx.download_segments()
         lo, hi = ctx.root_box()
     assert n_beams > 1200000 and n_segs > 20000000 and len(segs) == n_segs
@@ -126,8 +128,15 @@ def test_largest_configuration_band(pb):
         ref, cnt = orc.render_segments(orc.control_defaults(**kw), orc.tri_xyz(tri), orc.transformation_matrix(),
                                        segs, lo, hi, x, y0 + 4, 1, 16, step_x=1, step_y=8, mode=orc.MODE_73HET,
                                        grid_sigma=sigma, side=side)
-        got = whole[4::8, x][:16].astype(np.float64)
         small = ref[:, 0] < 1000.0                        # below the fixed-point saturation of single contributions
         assert small.mean() > 0.8 and cnt["valid_hits"] > 1000
-        err = np.abs(got - ref[:, 0])[small]
-        assert (err <= 1e-5 * np.maximum(1.0, np.abs(ref[:, 0][small]))).all(), err.max()
+        scale = np.maximum(1.0, np.abs(ref[:, 0][small]))
+        err = np.abs(exact[4::8, x][:16].astype(np.float64) - ref[:, 0])[small]
+        assert (err <= 1e-5 * scale).all(), err.max()
+        # the default estimator of a binned frame (relaxed arithmetic; records addressed beyond 2 GB): the stated bar
+        ferr = np.abs(whole[4::8, x][:16].astype(np.float64) - ref[:, 0])[small]
+        assert (ferr <= 2e-3 * scale).all(), ferr.max()
+    both = (whole < 1000.0) & (exact < 1000.0)
+    d = np.abs(whole.astype(np.float64) - exact)[both]
+    print(f"largest configuration, band: relaxed vs exact order max-abs {d.max():.3e} rmse {np.sqrt((d ** 2).mean()):.3e}")
+    assert (d <= 2e-3 * np.maximum(1.0, exact[both])).all() and np.sqrt((d ** 2).mean()) <= 1e-4

@@ -4,6 +4,8 @@ the photon pass with DDA-split segments, and the Integral_73Het estimator of BVH
 The reference holds no golden output for this branch (its screenshot is a homogeneous run), so the
 oracle functions checked here are pinned only by restating Heterogeneous.h / BeamRadiance.h:211-288;
 parity for them is "unpinned" in that sense."""
+import os
+
 import numpy as np
 import pytest
 
@@ -170,6 +172,16 @@ def test_het_render_matches_oracle(pb):
         lbvh = ctx.draw(mode=pb.MODE_73HET, cull="lbvh").astype(np.float64)
         fast = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)     # default: relaxed arithmetic
         fast2 = ctx.draw(mode=pb.MODE_73HET, cull="bins")
+        # the same kernel addressing records by their own 64-bit addresses (segment sets beyond 2 GB of records), behind
+        # either binning pass: the same bits
+        wide = []
+        for env in (dict(PB_TUNE_WIDE="1"), dict(PB_TUNE_WIDE="1", PB_TUNE_FUSED_MAX="0")):
+            os.environ.update(env)
+            try:
+                wide.extend(ctx.draw(mode=pb.MODE_73HET, cull="bins") for _ in range(2))
+            finally:
+                for k in env:
+                    del os.environ[k]
         ctx.set_precise(True)                                                   # the reference's operation order
         bins = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)
         bins2 = ctx.draw(mode=pb.MODE_73HET, cull="bins")
@@ -186,6 +198,7 @@ def test_het_render_matches_oracle(pb):
     assert np.array_equal(bins.astype(np.float32), bins2)
     # the relaxed-arithmetic estimator (closest approach from the cylinder roots, tabulated view-ray walk): the stated bar
     assert np.array_equal(fast.astype(np.float32), fast2)
+    assert all(np.array_equal(w, fast2) for w in wide)
     ferr = np.abs(fast[0::2, 1::2][:128, :128] - ref)
     print(f"73het relaxed arithmetic: max-abs {ferr.max():.3e} rmse {np.sqrt((ferr ** 2).mean()):.3e}, ref max {ref.max():.3f}")
     assert (ferr <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), ferr.max()
