@@ -284,6 +284,20 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       }
       p.walk = ws.d_walk;
     }
+    p.residue = nullptr; p.residue_capacity = 0;
+    if ((mode == PB_MODE_73HET || mode == PB_MODE_73) && !p.precise && !ws.fixed) {
+      // pairs the relaxed estimator cannot decide wait for a launch of their own, so that no item ends with a
+      // nearly empty wave running the exact-order code; an item whose pairs do not fit evaluates them itself
+      const int want = groups * 512 < (1 << 18) ? (1 << 18) : groups * 512;
+      if (want > ws.ws_residue_cap) {
+        if (ws.d_residue) PB_HIP(hipFree(ws.d_residue));
+        ws.d_residue = nullptr; ws.ws_residue_cap = 0;
+        PB_HIP(hipMalloc(&ws.d_residue, sizeof(uint2) * (size_t)want));
+        ws.ws_residue_cap = want;
+      }
+      p.residue = ws.d_residue; p.residue_capacity = ws.ws_residue_cap;
+      if (!pb_residue_frame(p, mode)) { p.residue = nullptr; p.residue_capacity = 0; }   // another kernel evaluates this frame
+    }
     {
       const size_t T = (size_t)ws.ws_tiles;
       p.tile_count = ws.d_tile_u32; p.item_off = ws.d_tile_u32 + T;
@@ -311,7 +325,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       // runs of 64 queue items per XCD: a tile's items share an L2 (cfg2: 91 -> 60 MB fetched by the evaluation, same
       // time; 512^2 / 1000 photons 0.0447 -> 0.0420 ms); frames with very many items lose 2 % to it and deal singly
       if (p.xcd_run < 0) p.xcd_run = ws.ws_items_needed <= (1 << 17) ? 64 : 0;
-      p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !std::getenv("PB_SEPARATE_FINALIZE")) ? 1 : 0;
+      p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !pb_residue_frame(p, mode) && !std::getenv("PB_SEPARATE_FINALIZE")) ? 1 : 0;
       rc = pb_launch_fast_frame(p, mode, s);
       if (rc != PB_OK) return rc;
       if (ctx->count_on || ctx->time_render) { PB_HIP(hipEventRecord(ctx->ev[1], s)); ctx->ev_valid[0] = true; }
@@ -347,12 +361,13 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       // candidate and drain a partly filled queue at the end of every item: they want longer items (cfg3:
       // 3.37 ms at 48, 3.08 at 96, 2.98 at 128..192, 3.11 at 256; its mean list is about 300).
       const bool queued = mode != PB_MODE_721;
-      // eval_items_het_kernel copies its rays' walk tables and ends with a drain of the pairs it left to the exact-order
-      // code, however few: longer items still (cfg3: 2.09 ms at 96, 1.57 at 192, 1.47 at 256, 1.38 at 384, 1.42 at 512)
+      // the relaxed-arithmetic kernels end an item with a partly filled drain of their queued pairs: longer items still
+      // (cfg3, eval_items_het2_kernel with the residue launch: 1.30 ms at 96, 1.21 at 128, 1.18 at 256, 1.21 at 384,
+      // 1.27 at 512; the one-pass kernel, which also copied its rays' walk tables: 2.09 / 1.57 / 1.47 / 1.38 / 1.42)
       const bool tabulated = queued && pb_pipelined_eval(p, mode);
       int want = (int)(mean_list / (tabulated ? 1 : (queued ? 2 : 6)) + 15) / 16 * 16;
       int longest = p.strip_stride >= 8 ? 48 : (p.strip_stride > 1 ? 96 : 128);   // a rank's share of strips has few items
-      if (queued) longest = tabulated ? longest * 3 : longest * 3 / 2;
+      if (queued) longest = tabulated ? (pb_residue_frame(p, mode) ? longest * 2 : longest * 3) : longest * 3 / 2;
       // very long lists mean hundreds of thousands of items: the per-item work (rays, planes, atomics) is worth
       // amortising over more candidates (1024^2, 106 381 segments, mean list 6743: 3.62 ms at 128, 3.50 at 256,
       // 3.43 at 384, 3.45 at 512; 512^2, 17 424 segments, mean list 1574: 0.198 ms at 128, 0.206 at 192)
@@ -444,6 +459,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   if (const char* e = std::getenv("PB_TUNE_XCDRUN")) { int v = std::atoi(e); if (v >= 0 && v <= 4096) p.xcd_run = v; }
   if (const char* e = std::getenv("PB_TUNE_WHOLE")) { int v = std::atoi(e); if (v >= 0 && v <= PB_SLICE) p.slice_whole = v; }
   p.eval_waves = ctx->tune_waves;
+  if (const char* e = std::getenv("PB_DEBUG_FLAGS")) p.debug = std::atoi(e);
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
 
@@ -561,7 +577,7 @@ void pb_destroy(pb_ctx* ctx) {
                   ctx->d_het, ctx->d_het_axis, ctx->d_het_fast, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
                   ctx->d_emit_tmp[1], ctx->ws.d_rays, ctx->ws.d_group_last,
                   ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list, ctx->ws.d_blk,
-                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->ws.d_walk, ctx->lb_pool};
+                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->ws.d_walk, ctx->ws.d_residue, ctx->lb_pool};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -629,7 +645,6 @@ int pb_set_grid(pb_ctx* ctx, const float* sigma_t, int side) {
   if (!ctx || !sigma_t || side < 2 || side > 4096) { pb_set_error("pb_set_grid: bad argument (2 <= side <= 4096)"); return PB_ERR_ARG; }
   int rc = ensure_device(ctx);
   if (rc != PB_OK) return rc;
-  if (ctx->d_grid) { PB_HIP(hipFree(ctx->d_grid)); ctx->d_grid = nullptr; ctx->grid_side = 0; ctx->grid_fast_div = 0; }
   const size_t n = (size_t)side * side;
   // the field, then (16-byte aligned) the four values of every cell index: GridView::cells() in pb_grid.h
   const size_t n_pad = (n + 3) & ~(size_t)3;
@@ -644,7 +659,15 @@ int pb_set_grid(pb_ctx* ctx, const float* sigma_t, int side) {
       c[2] = (col + 1 < side) ? sigma_t[i + 1] : sigma_t[i];
       c[3] = c[1];
     }
-  PB_HIP(hipMalloc(&ctx->d_grid, sizeof(float) * host.size()));
+  if (host.size() > ctx->grid_cap_floats) {
+    ctx->grid_side = 0; ctx->grid_fast_div = 0; ctx->grid_cap_floats = 0;
+    if (ctx->d_grid) { PB_HIP(hipFree(ctx->d_grid)); ctx->d_grid = nullptr; }
+    PB_HIP(hipMalloc(&ctx->d_grid, sizeof(float) * host.size()));
+    ctx->grid_cap_floats = host.size();
+  } else {
+    // the buffer is overwritten in place: frames still in flight on any stream read the field they were launched with
+    PB_HIP(hipDeviceSynchronize());
+  }
   PB_HIP(hipMemcpyAsync(ctx->d_grid, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, ctx->stream));
   PB_HIP(hipStreamSynchronize(ctx->stream));
   ctx->grid_side = side;

@@ -50,8 +50,21 @@ struct DdaWalk {
     guard = 0;
   }
 
+  // A sample whose four grid values have been requested and whose interpolation is still to do: fetch() then finish()
+  // is sample(); a loop that fetches sample i + 1 before it finishes sample i keeps a load in flight instead of waiting
+  // for each in turn.
+  struct Fetched { float tl, bl, tr, br, prop_x, prop_y; };
+  PB_DI static float finish(const Fetched& f) {
+    const float left = f.tl + ((f.bl - f.tl) * f.prop_y);
+    const float right = f.tr + ((f.br - f.tr) * f.prop_y);
+    float ext = left + ((right - left) * f.prop_x);
+    if (ext < 0) ext = 0;
+    return ext;
+  }
+  PB_DI float sample(const GridView& g, float dist, V3 index) const { return finish(fetch(g, dist, index)); }
+
   // Heterogeneous.h:144-180 for one sample
-  PB_DI float sample(const GridView& g, float dist, V3 index) const {
+  PB_DI Fetched fetch(const GridView& g, float dist, V3 index) const {
     const V3 p = o + (dir * dist);
     const V3 mn = v3(cell.x * index.x, cell.y * index.y, cell.z * index.z);
     const V3 dl = p - mn;
@@ -85,11 +98,9 @@ struct DdaWalk {
       t_l = min(max(t_l, 0), last); b_l = min(max(b_l, 0), last); t_r = min(max(t_r, 0), last);
       tl = g.z[t_l]; bl = g.z[b_l]; tr = g.z[t_r]; br = g.z[min(max(b_r, 0), last)];
     }
-    const float left = tl + ((bl - tl) * prop_y);
-    const float right = tr + ((br - tr) * prop_y);
-    float ext = left + ((right - left) * prop_x);
-    if (ext < 0) ext = 0;
-    return ext;
+    Fetched f;
+    f.tl = tl; f.bl = bl; f.tr = tr; f.br = br; f.prop_x = prop_x; f.prop_y = prop_y;
+    return f;
   }
 
   // One step of the walk (Heterogeneous.h:84-122): true when it leaves the grid or passes t_max, and the
@@ -249,17 +260,23 @@ PB_DI float view_walk_mean(const GridView& g, const ViewWalk& w, V3 l, float s, 
 PB_DI float extinction3d_mean(const GridView& g, V3 start, V3 end) {
   DdaWalk w;
   w.begin(g, start, end);
-  float sum = w.sample(g, 0.0f, w.idx);
+  // the samples are added in the reference's order; the values of sample i + 1 are requested before sample i is
+  // interpolated and added (where a step goes does not depend on what the grid holds)
+  DdaWalk::Fetched pending = w.fetch(g, 0.0f, w.idx);
+  float sum = 0.0f;
   int n = 1;
   for (;;) {
     float t;
     const bool done = w.advance(t);
     const V3 at = done ? w.prev : w.idx;
-    sum += w.sample(g, done ? w.t_max : t, at);
+    const DdaWalk::Fetched cur = w.fetch(g, done ? w.t_max : t, at);
+    sum += DdaWalk::finish(pending);
+    pending = cur;
     n++;
     if (done) break;
     w.prev = w.idx;
   }
+  sum += DdaWalk::finish(pending);
   return sum / (float)n;
 }
 

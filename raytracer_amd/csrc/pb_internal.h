@@ -127,6 +127,10 @@ struct RenderParams {
   const BeamAxis* het_axis; // per segment: beam_axis() of its end points (unused values for a cone record)
   const HetFast* het_fast;  // per segment, PB_MODE_73 / PB_MODE_73HET: what the relaxed-arithmetic estimator reads
   float* walk;              // [groups][VIEW_WALK_STRIDE][64] the view rays' tabulated walks through the grid, or null
+  uint2* residue;           // pairs the relaxed heterogeneous estimator leaves to the exact-order code and an item did not fill a
+                            // wave with: (segment, ray group * 64 + ray) in PB_RESIDUE_QUEUES queues; null: every item evaluates its own
+  int residue_capacity;
+  int debug;                // PB_DEBUG_FLAGS: timing experiments that leave work out (wrong frames); 0 in normal use
   int one_dimensional;     // ONE_DIMENSIONAL, read by PB_MODE_GENERIC
   int short_view;          // SHORT_VIEW
   uint32_t view_seed;      // Control seed: key of the camera rays' draws
@@ -226,6 +230,8 @@ struct FrameWorkspace {
   uint32_t* d_scan_tmp = nullptr;
   float* d_walk = nullptr;             // per ray group: the view rays' tabulated grid walks (heterogeneous medium only)
   int ws_walk_groups = 0;
+  uint2* d_residue = nullptr;          // device-wide queue of pairs for the exact-order code (relaxed heterogeneous estimator)
+  int ws_residue_cap = 0;
   int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_items_needed = 0;
   size_t ws_accum_px = 0;
   unsigned long long ws_key[6] = {0, 0, 0, 0, 0, 0};  // segment set + frame geometry the capacities were verified for
@@ -267,6 +273,7 @@ struct pb_ctx {
   HetFast* d_het_fast = nullptr;
   // extinction field of the heterogeneous medium
   float* d_grid = nullptr;
+  size_t grid_cap_floats = 0;      // floats d_grid holds: a new field of the same side (stop motion) reuses the buffer
   int grid_side = 0;
   int grid_fast_div = 0;   // the cell size passed pb_set_grid's division check (GridView::fast_div)
   int n_seg = 0, cap_seg = 0, frame_mode = 0;
@@ -341,10 +348,18 @@ PB_HDI int pb_mbin_blocks(int n_seg) { const int per = PB_MBIN_WAVES * pb_mbin_s
 PB_HDI uint32_t pb_item_slices(const RenderParams& p, uint32_t cnt) {
   return cnt <= (uint32_t)p.slice_whole ? (cnt ? 1u : 0u) : (cnt + (uint32_t)p.slice - 1u) / (uint32_t)p.slice;
 }
+// The residue queues of a relaxed-arithmetic heterogeneous frame (RenderParams::residue): items append to queue
+// (item index mod PB_RESIDUE_QUEUES), so that their atomics spread over as many addresses (one address takes about
+// 12 ns per atomic on this chip).  Layout in uint2 entries: PB_RESIDUE_HEAD entries of counters (queue q's at
+// 32-bit word q * 32, 128 bytes apart), then the queues, pb_residue_queue_capacity() entries each.
+constexpr int PB_RESIDUE_QUEUES = 256;
+constexpr int PB_RESIDUE_HEAD = PB_RESIDUE_QUEUES * 32 / 2;
+PB_HDI uint32_t pb_residue_queue_capacity(int total_entries) { return (uint32_t)(total_entries - PB_RESIDUE_HEAD) / (uint32_t)PB_RESIDUE_QUEUES; }
 PB_HDI int pb_macro_count(const RenderParams& p) {
   return ((p.tiles_x + p.macro_w - 1) / p.macro_w) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
 }
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s);
 int pb_launch_fast_frame(const RenderParams& p, int mode, hipStream_t s);
+bool pb_residue_frame(const RenderParams& p, int mode);   // the frame's evaluation hands pairs to a residue launch (pixels written after it)
 
 #endif

@@ -553,6 +553,51 @@ PB_DI int pair_het_fast_geometry(const float Rinv[9], float ox2, float oz2, floa
   return 2;
 }
 
+// pair_het_fast_geometry without branches: every lane runs every stage (as soon as one lane of a wave passes a stage the
+// wave issues it anyway; the nested exits only add execution-mask bookkeeping) and the outcome is put together from
+// predicates at the end.  The arithmetic of a lane that passes a stage is the same, operation for operation, so the
+// outcome is the same.  ok: a crossing whose closest approach lies inside it (return value 2 there); defer: undecided (3).
+PB_DI void pair_het_fast_geometry_flat(const float Rinv[9], float ox2, float oz2, float c4, float oy, float len, const Ray& r,
+                                       bool& ok_out, bool& defer_out, float& tc_minus_out, float& t_mid_out, float& y_star_out,
+                                       float& y_err_out, float& sin2_out) {
+  const V3 l = r.l;
+  const float dpx = Rinv[0] * l.x + Rinv[3] * l.y + Rinv[6] * l.z;
+  const float dpz = Rinv[2] * l.x + Rinv[5] * l.y + Rinv[8] * l.z;
+  const float a = dpx * dpx + dpz * dpz;
+  const float b = ox2 * dpx + oz2 * dpz;
+  const float b24ac = b * b - a * c4;
+  const bool hit = !(b24ac < 0);
+  const bool end_on = !(a >= HET_FAST_MIN_SIN2);
+  const float sq = __builtin_amdgcn_sqrtf(b24ac);
+  const float inv2a = fast_rcp(a + a);
+  const float t0 = (-b - sq) * inv2a;
+  const float t1 = (-b + sq) * inv2a;
+  const bool ordered = (t0 > 0) & (t1 > t0);
+  const float dpy = __builtin_fmaf(Rinv[7], l.z, __builtin_fmaf(Rinv[4], l.y, Rinv[1] * l.x));
+  const float y0 = __builtin_fmaf(t0, dpy, oy);
+  const float y1 = __builtin_fmaf(t1, dpy, oy);
+  const float y_err = 2e-6f * (fabsf(oy) + fabsf(t1 * dpy));
+  const bool in_caps = !((fmaxf(y0, y1) < -y_err) | (fminf(y0, y1) > 1.0f + y_err));
+  const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);
+  const float sy = __builtin_amdgcn_fmed3f(y1, 0.0f, 1.0f);
+  const float q = -fast_rcp(dpy);
+  const float thf = t0 + mul_zero_wins(y0 - fy, q);
+  const float ths = t1 + mul_zero_wins(y1 - sy, q);
+  const float t_mid = -b * inv2a;
+  tc_minus_out = thf * len;
+  const float noise = 2.5e-7f * t_mid * fast_rcp(fmaxf(ths - thf, 1e-30f) * a);
+  const float edge = fmaxf(HET_FAST_EDGE, noise) * t_mid + y_err * fabsf(q);
+  y_err_out = y_err + edge;
+  const bool outside = (t_mid < thf - edge) | (t_mid > ths + edge);
+  const bool near = (t_mid < thf + edge) | (t_mid > ths - edge);
+  const bool base = hit & !end_on & ordered & in_caps & !outside;
+  ok_out = base & !near;
+  defer_out = hit & (end_on | (base & near));
+  t_mid_out = t_mid;
+  y_star_out = __builtin_fmaf(t_mid, dpy, oy);
+  sin2_out = a;
+}
+
 // log2_scale: the integral is returned times 2^log2_scale (folded into the exponential at no cost).
 template <bool CHECK>
 PB_DI int eval_pair_721_fast(const SegFrame& f, const Ray& r, float extinction, double& integral_out, unsigned long long& shortcut_wrong,

@@ -510,6 +510,10 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
   const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
   const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + (lane >> 3);
   const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
+  if (p.residue && group == 0) {      // the frame's residue queues start empty
+    uint32_t* counters = (uint32_t*)p.residue;
+    for (int q = lane; q < PB_RESIDUE_QUEUES; q += 64) counters[q * 32] = 0u;
+  }
   if (p.fused_queue) {
     // this launch also clears the pixel sums the frame accumulates into (the bin counters are cleared by
     // the previous frame's finalize_kernel)
@@ -1452,6 +1456,17 @@ PB_DI void smem_load16_first(u32x16& dst, const SegFrame* rec) { asm volatile("s
 PB_DI void smem_load16_second(u32x16& dst, const SegFrame* rec) { asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=&s"(dst) : "s"(rec)); }
 PB_DI void smem_load8_at(u32x8& dst, const HetFast* rec) { asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(dst) : "s"(rec)); }
 
+// A lane's own copy of a segment's record, fetched as twelve 16-byte loads: field by field, a wave whose lanes read 64
+// different records issues some forty-five loads of 64 scattered dwords each.
+PB_DI SegFrame load_frame_wide(const SegFrame* src) {
+  SegFrame f;
+  const uint4* s4 = (const uint4*)src;
+  uint4* d4 = (uint4*)&f;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(SegFrame) / 16); ++i) d4[i] = s4[i];
+  return f;
+}
+
 struct HetItem {
   const SegFrame* frames;
   const HetFast* het;
@@ -1621,7 +1636,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
       rq.maxd = rr[6 * 64 + rl];
       rq.d1 = v3(rr[8 * 64 + rl], rr[9 * 64 + rl], rr[10 * 64 + rl]);
       rq.active = true;
-      const SegFrame& f = p.frames[sidx];
+      const SegFrame f = load_frame_wide(p.frames + sidx);
       CylHit hit;
       if (hit_cylinder_exact(f, rq, hit) == 2) {
         const float4 A = p.capA[sidx];
@@ -1681,6 +1696,263 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
       sum.nc++;
     }
   }
+  item_writeout<FINALIZE>(p, tile, lane, sum);
+}
+
+// The same estimator with its two halves run apart.  In eval_items_het_kernel every lane of the wave goes through the whole
+// pair - cylinder crossing, then the axis point's bounds, the tabulated walk, the exponential, the fixed-point sums -
+// although only about one (ray, survivor) pair in four has a crossing whose closest approach lies inside it: as long as
+// one lane does, the wave issues it all.  Here the pair loop (wave-uniform record through the scalar cache, as before) ends
+// with the crossing and the gate; the lanes that passed queue (segment, ray, t_mid, y*, margin, sin^2) in LDS, and whenever
+// 64 are waiting every lane takes one - whatever ray it belongs to - fetches what it needs of the segment's records with
+// vector loads, evaluates the rest and adds its term to that ray's sums in LDS (fixed point: the order does not matter).
+// The rays' walk tables stay in global memory (three look-ups per queued pair, served by the caches; in LDS they were
+// 10 KB a wave and held the kernel to three waves per SIMD).
+constexpr int FAST_QUEUE = 192;       // up to 63 waiting + two survivors' worth of lanes between two looks at the queue
+constexpr int EXACT_QUEUE = 192;      // likewise: 63 + two survivors, or 63 + what one drain of the fast queue hands over
+template <bool FINALIZE, bool WIDE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void eval_items_het2_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  __shared__ uint32_t fq_key[FAST_QUEUE];                 // segment * 64 + ray (lane) of a pair whose crossing holds its closest approach
+  __shared__ float fq_val[4][FAST_QUEUE];                 // t_mid, y*, the margin on y*, sin^2(theta)
+  __shared__ uint32_t q_seg[EXACT_QUEUE], q_ray[EXACT_QUEUE]; // pairs left to the exact-order code
+  __shared__ unsigned long long s_acc[4][64];             // per ray: red, green, blue, and what all three share
+  __shared__ float s_d1len[64];
+  const int lane = threadIdx.x;
+  const uint32_t produced = p.ctrl[0];
+  const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
+  uint32_t c = blockIdx.x;
+  if (p.xcd_run > 0) {
+    const uint32_t run_len = (uint32_t)p.xcd_run, xcd = c & 7u, j = c >> 3;
+    c = ((j / run_len) * 8u + xcd) * run_len + j % run_len;
+  }
+  if (c >= n_items) return;
+  const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
+  const int group = (int)it[0];
+  const uint32_t start = it[1];
+  const int cn = (int)it[2];
+  const int tile = group / (p.ssaa * p.ssaa);
+  const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+  V3 pl[4];
+  {
+    const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
+    pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
+  }
+  Ray r;
+  r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+  r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
+  r.maxd = rr[6 * 64 + lane];
+  r.d1 = r.dn;
+  r.active = r.maxd >= 0.0f;
+  s_d1len[lane] = length3(v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]));
+  int ns = 0;
+  for (int base = 0; base < cn; base += 64) {
+    const int k = base + lane;
+    const uint32_t cand = (k < cn) ? p.bin_list[start + k] : 0xffffffffu;
+    bool touch = false;
+    if (cand != 0xffffffffu) touch = axis_touches_pyramid(p.capA[cand], p.capB[cand], pl);
+    const unsigned long long mask = __ballot(touch);
+    if (touch) surv[ns + (int)lanes_below(mask)] = cand;
+    ns += __builtin_popcountll(mask);
+  }
+  s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull; s_acc[3][lane] = 0ull;
+  __syncthreads();
+  GridView grid;
+  grid.z = p.grid_z; grid.side = p.grid_side; grid.fast_div = p.grid_fast_div;
+  const float* wt = p.walk ? p.walk + (size_t)group * VIEW_WALK_STRIDE * 64 : nullptr;   // the group's walk tables, then its rays' ViewWalk members
+  const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
+  int pending = 0, waiting = 0;          // entries of the exact-order queue, of the fast queue
+  auto push_exact = [&](unsigned long long mask, uint32_t sidx, uint32_t ray) __attribute__((always_inline)) {
+    if ((mask >> lane) & 1ull) {
+      const int e = pending + (int)lanes_below(mask);
+      q_seg[e] = sidx; q_ray[e] = ray;
+    }
+    pending += __builtin_popcountll(mask);
+  };
+  auto drain_exact = [&](int take) __attribute__((always_inline)) {
+    __syncthreads();
+    if (lane < take) {
+      const int e = pending - take + lane;
+      const uint32_t sidx = q_seg[e], rl = q_ray[e];
+      Ray rq;
+      rq.l = v3(rr[0 * 64 + rl], rr[1 * 64 + rl], rr[2 * 64 + rl]);
+      rq.dn = v3(rr[3 * 64 + rl], rr[4 * 64 + rl], rr[5 * 64 + rl]);
+      rq.maxd = rr[6 * 64 + rl];
+      rq.d1 = v3(rr[8 * 64 + rl], rr[9 * 64 + rl], rr[10 * 64 + rl]);
+      rq.active = true;
+      const SegFrame f = load_frame_wide(p.frames + sidx);
+      CylHit hit;
+      if (hit_cylinder_exact(f, rq, hit) == 2) {
+        const float4 A = p.capA[sidx];
+        double integral = integral_73het(grid, v3(A.x, A.y, A.z), p.het[sidx], p.het_axis[sidx], hit, rq, p.extinction_c, p.scattering_c);
+        const double W0 = f.W[0], W1 = f.W[1], W2 = f.W[2];
+        integral = fmin(integral, PB_FIX_LIMIT / fmax(W0, fmax(W1, W2)));
+        integral = integral * PB_FIX_PRESCALE;
+        const unsigned long long v0 = (unsigned long long)__double_as_longlong(__builtin_fma(W0, integral, PB_FIX_MAGIC)) - magic_bits;
+        const unsigned long long v1 = (unsigned long long)__double_as_longlong(__builtin_fma(W1, integral, PB_FIX_MAGIC)) - magic_bits;
+        const unsigned long long v2 = (unsigned long long)__double_as_longlong(__builtin_fma(W2, integral, PB_FIX_MAGIC)) - magic_bits;
+        if (v0) atomicAdd(&s_acc[0][rl], v0);
+        if (v1) atomicAdd(&s_acc[1][rl], v1);
+        if (v2) atomicAdd(&s_acc[2][rl], v2);
+      }
+    }
+    pending -= take;
+    __syncthreads();
+  };
+  // the second half of the estimator for the top `take` entries of the fast queue, one per lane
+  auto drain_fast = [&](int take) __attribute__((always_inline)) {
+    __syncthreads();
+    bool defer = false;
+    uint32_t sidx = 0, rl = 0;
+    if (lane < take) {
+      const int e = waiting - take + lane;
+      const uint32_t key = fq_key[e];
+      sidx = key >> 6; rl = key & 63u;
+      const float t_mid = fq_val[0][e], y_star = fq_val[1][e], y_err = fq_val[2][e], sin2 = fq_val[3][e];
+      const float4* rec = (const float4*)(p.frames + sidx);
+      const float4 a3 = rec[3];                               // oy, len, tb0, qflags
+      const float4 b0 = rec[4];                               // W[0], W[1]
+      const float2 b1 = ((const float2*)rec)[10];             // W[2]
+      const float vcap10 = ((const float*)rec)[31];
+      const float4* hrec = (const float4*)(p.het_fast + sidx);
+      const float4 h0 = hrec[0], h1 = hrec[1];                // r2, osy, aos, bos | A, B, krad, -
+      const float len = a3.y;
+      const uint32_t qflags = __builtin_bit_cast(uint32_t, a3.w);
+      // distance of the axis point from orig_start, within [|start - orig_start|, |end - orig_start|] (BeamRadiance.h:248)
+      const float dy = y_star - h0.y;
+      const float beta = __builtin_amdgcn_sqrtf(__builtin_fmaf(dy, dy, h0.x));
+      const float edge = HET_FAST_EDGE * h0.w + y_err;
+      const bool ok = (beta >= h0.z + edge) && (beta <= h0.w - edge);
+      defer = !ok && (beta >= h0.z - edge) && (beta <= h0.w + edge);
+      if (ok) {
+        const float view_distance = t_mid * len;
+        const float beam_extinction = __builtin_fmaf(h1.y, beta - h0.z, h1.x);
+        float view_extinction = p.extinction_c;
+        if (grid.z) {
+          const float cut = view_distance * s_d1len[rl];
+          const ViewWalk w = view_walk_load(wt + VIEW_WALK_ROWS * 64, (int)rl);
+          defer = cut >= w.t_unsure;           // the exact-order code evaluates this pair; the term added below is zero
+          view_extinction = view_walk_mean(grid, w, v3(rr[0 * 64 + rl], rr[1 * 64 + rl], 0.0f), cut, wt, (int)rl);
+        }
+        const float depth = __builtin_fmaf(beam_extinction * beta, len, view_extinction * view_distance);
+        const float transmitted = __builtin_amdgcn_exp2f(__builtin_fmaf(depth, -1.44269504f, -10.0f));   // times the 2^-10 of the sums
+        float value = transmitted * beam_extinction * h1.z * __builtin_amdgcn_rsqf(sin2);
+        if (transmitted < 1e-6f * 0.0009765625f || defer) value = 0.0f;                                   // BeamRadiance.h:273
+        const double integral = (double)__builtin_amdgcn_fmed3f(value, 0.0f, vcap10);
+        const double W0 = __builtin_bit_cast(double, make_float2(b0.x, b0.y));
+        if (qflags & 64u) {
+          const unsigned long long v = (unsigned long long)__double_as_longlong(__builtin_fma(W0, integral, PB_FIX_MAGIC)) - magic_bits;
+          if (v) atomicAdd(&s_acc[3][rl], v);
+        } else {
+          const double W1 = __builtin_bit_cast(double, make_float2(b0.z, b0.w)), W2 = __builtin_bit_cast(double, b1);
+          const unsigned long long v0 = (unsigned long long)__double_as_longlong(__builtin_fma(W0, integral, PB_FIX_MAGIC)) - magic_bits;
+          const unsigned long long v1 = (unsigned long long)__double_as_longlong(__builtin_fma(W1, integral, PB_FIX_MAGIC)) - magic_bits;
+          const unsigned long long v2 = (unsigned long long)__double_as_longlong(__builtin_fma(W2, integral, PB_FIX_MAGIC)) - magic_bits;
+          if (v0) atomicAdd(&s_acc[0][rl], v0);
+          if (v1) atomicAdd(&s_acc[1][rl], v1);
+          if (v2) atomicAdd(&s_acc[2][rl], v2);
+        }
+      }
+    }
+    waiting -= take;
+    const unsigned long long dm = __ballot(defer);
+    if (dm) push_exact(dm, sidx, rl);
+    __syncthreads();
+  };
+  if (ns > 32) __builtin_amdgcn_s_setprio(3);
+  else if (ns > 16) __builtin_amdgcn_s_setprio(2);
+  else if (ns > 8) __builtin_amdgcn_s_setprio(1);
+  // one survivor: the crossing for every lane's ray; `cur` holds the first half of its record, the gate box comes with the
+  // second half, and the first half of the next survivor's record is requested into `nxt`
+  auto step = [&](u32x16& cur, u32x16& nxt, uint32_t idx_cur, uint32_t idx_nxt) __attribute__((always_inline)) {
+    u32x16 second;
+    if (WIDE) {
+      smem_load16_second(second, p.frames + idx_cur);
+      smem_load16_first(nxt, p.frames + idx_nxt);
+    } else {
+      smem_load16(second, p.frames, idx_cur * (uint32_t)sizeof(SegFrame) + 64u);
+      smem_load16(nxt, p.frames, idx_nxt * (uint32_t)sizeof(SegFrame));
+    }
+    SegHalfA a;
+    __builtin_memcpy(&a, &cur, 64);
+    float tc_minus, t_mid, y_star, y_err, sin2;
+    bool ok, undecided;
+    pair_het_fast_geometry_flat(a.Rinv, a.ox2, a.oz2, a.c4, a.oy, a.len, r, ok, undecided, tc_minus, t_mid, y_star, y_err, sin2);
+    smem_wait(second, nxt);
+    SegHalfB b;
+    __builtin_memcpy(&b, &second, 64);
+    if (ok && !pair_721_fast_sure(a.qflags, tc_minus, r.maxd)) ok = pair_721_fast_gate(b.lo, b.hi, b.cand, a.qflags, r);
+    const unsigned long long km = __ballot(ok);
+    if (km) {
+      if (ok) {
+        const int e = waiting + (int)lanes_below(km);
+        fq_key[e] = (idx_cur << 6) | (uint32_t)lane;
+        fq_val[0][e] = t_mid; fq_val[1][e] = y_star; fq_val[2][e] = y_err; fq_val[3][e] = sin2;
+      }
+      waiting += __builtin_popcountll(km);
+    }
+    const unsigned long long dm = __ballot(undecided && r.active);
+    if (dm) push_exact(dm, idx_cur, (uint32_t)lane);
+  };
+  // Survivors in blocks of 64 (their indices in a register, picked with v_readlane), two to an iteration; the queues are
+  // looked at between iterations and drained from one place each (a drain is thousands of instructions long).
+  {
+    int b0 = 0, k = 0, nb = 0, mine = 0;
+    uint32_t idx_cur = 0;
+    u32x16 ra, rb;
+    bool need_block = true;
+    for (;;) {
+      const bool flushing = need_block && b0 >= ns;
+      if (!FINALIZE && flushing && waiting == 0 && pending > 0 && pending < 64 && p.residue) {
+        // fewer than a wave's worth left: they join one of the frame's residue queues (residue_kernel) if it has room
+        const uint32_t q = c & (uint32_t)(PB_RESIDUE_QUEUES - 1);
+        const uint32_t cap = pb_residue_queue_capacity(p.residue_capacity);
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd((uint32_t*)p.residue + q * 32u, (uint32_t)pending);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        const bool fits = at + (uint32_t)pending <= cap;
+        __syncthreads();
+        uint2* dst = p.residue + PB_RESIDUE_HEAD + (size_t)q * cap;
+        if (lane < pending && at + (uint32_t)lane < cap)
+          dst[at + lane] = fits ? make_uint2(q_seg[lane], ((uint32_t)group << 6) | q_ray[lane]) : make_uint2(0xffffffffu, 0u);
+        if (fits) { pending = 0; continue; }
+      }
+      if (pending >= 64 || (flushing && waiting == 0 && pending > 0)) { drain_exact(pending < 64 ? pending : 64); continue; }
+      if (waiting >= 64 || (flushing && waiting > 0)) { drain_fast(waiting < 64 ? waiting : 64); continue; }
+      if (flushing) break;
+      if (need_block) {
+        nb = (ns - b0) < 64 ? (ns - b0) : 64;
+        mine = (lane < nb) ? (int)surv[b0 + lane] : 0;
+        idx_cur = (uint32_t)__builtin_amdgcn_readlane(mine, 0);
+        if (WIDE) smem_load16_first(ra, p.frames + idx_cur);
+        else smem_load16(ra, p.frames, idx_cur * (uint32_t)sizeof(SegFrame));
+        smem_wait(ra);
+        k = 0;
+        need_block = false;
+      }
+      if (k + 1 < nb) {
+        const uint32_t idx1 = (uint32_t)__builtin_amdgcn_readlane(mine, k + 1);
+        const int k2 = (k + 2 < nb) ? k + 2 : nb - 1;
+        const uint32_t idx2 = (uint32_t)__builtin_amdgcn_readlane(mine, k2);
+        step(ra, rb, idx_cur, idx1);
+        step(rb, ra, idx1, idx2);
+        idx_cur = idx2;
+        k += 2;
+      } else {
+        step(ra, rb, idx_cur, idx_cur);
+        k += 1;
+      }
+      if (k >= nb) { b0 += 64; need_block = true; }
+    }
+  }
+  __syncthreads();
+  // the sums in LDS carry no anchor: they join the write-out as one term each
+  PairSums sum;
+  const unsigned long long a0 = s_acc[0][lane], a1 = s_acc[1][lane], a2 = s_acc[2][lane], ag = s_acc[3][lane];
+  sum.nc = (a0 | a1 | a2) ? 1u : 0u;
+  sum.ng = ag ? 1u : 0u;
+  sum.ai[0] = a0 + (sum.nc ? magic_bits : 0ull); sum.ai[1] = a1 + (sum.nc ? magic_bits : 0ull); sum.ai[2] = a2 + (sum.nc ? magic_bits : 0ull);
+  sum.ag = ag + (sum.ng ? magic_bits : 0ull);
   item_writeout<FINALIZE>(p, tile, lane, sum);
 }
 
@@ -1821,6 +2093,89 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
 }
 
+// The pairs the items of a relaxed-arithmetic heterogeneous frame handed over (eval_items_het2_kernel), 64 to a wave:
+// the exact-order estimate of each, added to its pixel's sums in memory (fixed point: in any order).
+constexpr int RESIDUE_BLOCKS_PER_QUEUE = 32;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void residue_kernel(const RenderParams p) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x & (uint32_t)(PB_RESIDUE_QUEUES - 1), part = blockIdx.x / (uint32_t)PB_RESIDUE_QUEUES;
+  const uint32_t cap = pb_residue_queue_capacity(p.residue_capacity);
+  const uint32_t queued = pb_uniform((const uint32_t*)p.residue)[q * 32u];
+  const uint32_t n = queued < cap ? queued : cap;
+  const uint2* src = p.residue + PB_RESIDUE_HEAD + (size_t)q * cap;
+  const int nsub = p.ssaa * p.ssaa;
+  GridView grid;
+  grid.z = p.grid_z; grid.side = p.grid_side; grid.fast_div = p.grid_fast_div;
+  const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
+  // Pairs of one pixel are pooled in LDS before they reach its sums in memory: a pixel that looks along a beam has
+  // dozens of them in a batch, and atomics on one address take about 12 ns each.  A lane's pool slot is a hash of its
+  // pixel; where two pixels of a batch share a slot the slot's last writer pools and the other adds directly.
+  __shared__ uint32_t s_key[64];
+  __shared__ unsigned long long s_v[3][64];
+  constexpr uint32_t NONE = 0xffffffffu;
+  for (uint32_t base = part * 64u; base < n; base += RESIDUE_BLOCKS_PER_QUEUE * 64u) {
+    const uint32_t e = base + (uint32_t)lane;
+    uint32_t key = NONE;
+    unsigned long long v0 = 0ull, v1 = 0ull, v2 = 0ull;
+    if (e < n && !(p.debug & 4)) {
+      const uint2 ent = src[e];
+      const uint32_t sidx = ent.x;                       // NONE: a slot of a batch that did not fit (its item evaluated it)
+      if (sidx != NONE) {
+        key = ent.y;
+        const uint32_t group = key >> 6, rl = key & 63u;
+        const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+        Ray rq;
+        rq.l = v3(rr[0 * 64 + rl], rr[1 * 64 + rl], rr[2 * 64 + rl]);
+        rq.dn = v3(rr[3 * 64 + rl], rr[4 * 64 + rl], rr[5 * 64 + rl]);
+        rq.maxd = rr[6 * 64 + rl];
+        rq.d1 = v3(rr[8 * 64 + rl], rr[9 * 64 + rl], rr[10 * 64 + rl]);
+        rq.active = true;
+        const SegFrame f = load_frame_wide(p.frames + sidx);
+        CylHit hit;
+        if (hit_cylinder_exact(f, rq, hit) == 2) {
+          const float4 A = p.capA[sidx];
+          double integral = (p.debug & 2) ? 1.0 : integral_73het(grid, v3(A.x, A.y, A.z), p.het[sidx], p.het_axis[sidx], hit, rq, p.extinction_c, p.scattering_c);
+          const double W0 = f.W[0], W1 = f.W[1], W2 = f.W[2];
+          integral = fmin(integral, PB_FIX_LIMIT / fmax(W0, fmax(W1, W2)));
+          integral = integral * PB_FIX_PRESCALE;
+          v0 = (unsigned long long)__double_as_longlong(__builtin_fma(W0, integral, PB_FIX_MAGIC)) - magic_bits;
+          v1 = (unsigned long long)__double_as_longlong(__builtin_fma(W1, integral, PB_FIX_MAGIC)) - magic_bits;
+          v2 = (unsigned long long)__double_as_longlong(__builtin_fma(W2, integral, PB_FIX_MAGIC)) - magic_bits;
+        }
+      }
+    }
+    if (p.debug & 1) continue;
+    const uint32_t slot = (key ^ ((key >> 6) * 29u)) & 63u;
+    s_v[0][lane] = 0ull; s_v[1][lane] = 0ull; s_v[2][lane] = 0ull;
+    if (key != NONE) s_key[slot] = key;
+    __syncthreads();
+    if (key != NONE) {
+      if (s_key[slot] == key) {
+        if (v0) atomicAdd(&s_v[0][slot], v0);
+        if (v1) atomicAdd(&s_v[1][slot], v1);
+        if (v2) atomicAdd(&s_v[2][slot], v2);
+      } else {
+        unsigned long long* dst = p.accum + (size_t)((key >> 6) / (uint32_t)nsub) * PB_ACC_PLANES * 64 + (key & 63u);
+        if (v0) atomicAdd(&dst[0], v0);
+        if (v1) atomicAdd(&dst[64], v1);
+        if (v2) atomicAdd(&dst[128], v2);
+      }
+    }
+    __syncthreads();
+    {
+      const unsigned long long a0 = s_v[0][lane], a1 = s_v[1][lane], a2 = s_v[2][lane];
+      if (a0 | a1 | a2) {                              // this batch pooled something in slot `lane`: s_key[lane] is its pixel
+        const uint32_t k2 = s_key[lane];
+        unsigned long long* dst = p.accum + (size_t)((k2 >> 6) / (uint32_t)nsub) * PB_ACC_PLANES * 64 + (k2 & 63u);
+        if (a0) atomicAdd(&dst[0], a0);
+        if (a1) atomicAdd(&dst[64], a1);
+        if (a2) atomicAdd(&dst[128], a2);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void beam_axis_kernel(const float4* __restrict__ capA, const float4* __restrict__ capB,
                                                        const HetFrame* __restrict__ het, int n, BeamAxis* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1848,6 +2203,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
 int pb_fused_queue_macros(void) { return QUEUE_FUSED_MACROS; }
 
 // Whether an uncounted frame of `mode` is evaluated by eval_items_fast_kernel (one wave per item, 32-bit record offsets).
+static bool het_two_pass(const RenderParams& p) { return p.n_seg < (1 << 26) && !std::getenv("PB_TUNE_HET1"); }
 static bool wide_records(const RenderParams& p) { return (size_t)p.n_seg * sizeof(SegFrame) >= ((size_t)1 << 31); }
 bool pb_pipelined_eval(const RenderParams& p, int mode) {
   if (p.precise || p.eval_waves > 0 || std::getenv("PB_OLD_EVAL")) return false;
@@ -1857,6 +2213,11 @@ bool pb_pipelined_eval(const RenderParams& p, int mode) {
   if (mode == PB_MODE_73 || mode == PB_MODE_73HET)
     return p.het_fast && (!p.grid_z || (p.walk && p.grid_side >= 2 && p.grid_side <= VIEW_WALK_MAX_SIDE));
   return false;
+}
+
+bool pb_residue_frame(const RenderParams& p, int mode) {
+  return (mode == PB_MODE_73 || mode == PB_MODE_73HET) && p.residue && pb_pipelined_eval(p, mode) && het_two_pass(p) &&
+         !std::getenv("PB_TUNE_NO_RESIDUE");
 }
 
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
@@ -1966,13 +2327,25 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
       if (p.grid_z) hipLaunchKernelGGL(view_walk_kernel, dim3(p.tiles_x * p.tiles_y * p.ssaa * p.ssaa), dim3(64), 0, s, p);
       if (p.xcd_run > 0) waves = (waves + 8 * p.xcd_run - 1) / (8 * p.xcd_run) * (8 * p.xcd_run);    // whole runs for every XCD
       const bool wide = wide_records(p) || std::getenv("PB_TUNE_WIDE") != nullptr;
-      if (p.finalize_in_eval) {
-        if (wide) hipLaunchKernelGGL((eval_items_het_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
+      // eval_items_het2_kernel (the estimator's second half run on queued pairs, 64 to a wave) packs segment and ray
+      // into 32 bits; PB_TUNE_HET1 selects the one-pass kernel
+      const bool two_pass = het_two_pass(p);
+      if (pb_residue_frame(p, mode)) {
+        // the items hand the pairs they leave to the exact-order code to one more launch; the pixels are written after it
+        if (wide) hipLaunchKernelGGL((eval_items_het2_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((eval_items_het2_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(residue_kernel, dim3(PB_RESIDUE_QUEUES * RESIDUE_BLOCKS_PER_QUEUE), dim3(64), 0, s, p);
+      } else if (p.finalize_in_eval) {
+        if (two_pass && wide) hipLaunchKernelGGL((eval_items_het2_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
+        else if (two_pass) hipLaunchKernelGGL((eval_items_het2_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
+        else if (wide) hipLaunchKernelGGL((eval_items_het_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
         else hipLaunchKernelGGL((eval_items_het_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
         PB_HIP(hipGetLastError());
         return PB_OK;
       }
-      if (wide) hipLaunchKernelGGL((eval_items_het_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
+      else if (two_pass && wide) hipLaunchKernelGGL((eval_items_het2_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
+      else if (two_pass) hipLaunchKernelGGL((eval_items_het2_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
+      else if (wide) hipLaunchKernelGGL((eval_items_het_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
       else hipLaunchKernelGGL((eval_items_het_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
     }
     else hipLaunchKernelGGL(eval_bins_queue_kernel<PB_MODE_73HET>, dim3(waves), dim3(64), 0, s, p);

@@ -36,7 +36,7 @@ PASSES = {
 # kernels of the one-time passes and of the counted (untimed) frame are left out of the per-frame sums
 NOT_FRAME = ("emit_kernel", "bound_kernel", "sort_", "scan_", "add_offsets", "karras", "node_box", "leaf_box", "root_box",
              "morton", "pack_kernel", "box_union", "bounds_kernel", "prepare_", "beam_axis", "at::native", "__amd_rocclr",
-             "<true,", "ray_setup_kernel<true>", "lbvh_", "small_sort", "ncclDevKernel")
+             "eval_bins_kernel<true,", "eval_kernel<true,", "ray_setup_kernel<true>", "lbvh_", "small_sort", "ncclDevKernel")
 
 
 def source_stamp():

@@ -1,0 +1,7 @@
+#!/bin/bash
+# residue_kernel time with parts of its work left out (PB_DEBUG_FLAGS: 1 no atomics, 2 no integral, 4 nothing); on the GPU box
+for f in 0 1 2 4; do
+  export PB_DEBUG_FLAGS=$f
+  timeout -k 10 300 python tools/profile_frame.py cfg3 gpurun_out/s4_resexp_$f trace > /dev/null || exit 1
+  echo "flags $f: $(grep residue_kernel gpurun_out/s4_resexp_$f/cfg3_kernel_stats.csv | cut -d, -f1,4)  $(grep 'eval_items_het2' gpurun_out/s4_resexp_$f/cfg3_kernel_stats.csv | cut -d, -f1,4 | head -1)"
+done
