@@ -1771,7 +1771,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
   };
   auto drain_exact = [&](int take) __attribute__((always_inline)) {
     __syncthreads();
-    if (lane < take) {
+    if (lane < take && !(p.debug & 16)) {
       const int e = pending - take + lane;
       const uint32_t sidx = q_seg[e], rl = q_ray[e];
       Ray rq;
@@ -1804,7 +1804,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
     __syncthreads();
     bool defer = false;
     uint32_t sidx = 0, rl = 0;
-    if (lane < take) {
+    if (lane < take && !(p.debug & 8)) {
       const int e = waiting - take + lane;
       const uint32_t key = fq_key[e];
       sidx = key >> 6; rl = key & 63u;
@@ -2203,8 +2203,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(const RenderParams p) {
 int pb_fused_queue_macros(void) { return QUEUE_FUSED_MACROS; }
 
 // Whether an uncounted frame of `mode` is evaluated by eval_items_fast_kernel (one wave per item, 32-bit record offsets).
-static bool het_two_pass(const RenderParams& p) { return p.n_seg < (1 << 26) && !std::getenv("PB_TUNE_HET1"); }
 static bool wide_records(const RenderParams& p) { return (size_t)p.n_seg * sizeof(SegFrame) >= ((size_t)1 << 31); }
+// The two-pass kernel wins where valid crossings are a minority of a tile's (ray, survivor) pairs and the records it
+// fetches per lane stay in the caches (236 629 segments at 512^2: 1.09 against 1.42 ms; 2.4 M: 12.4 against 13.6 ms); over
+// the 23.7 M segments (4.5 GB of records) of the largest configuration, whose frame is mostly the cone, the one-pass
+// kernel is faster (2.85 against 3.43 s).  PB_TUNE_HET1 / PB_TUNE_HET2 force one or the other.
+static bool het_two_pass(const RenderParams& p) {
+  if (std::getenv("PB_TUNE_HET1") || p.n_seg >= (1 << 26)) return false;
+  return !wide_records(p) || std::getenv("PB_TUNE_HET2") != nullptr;
+}
 bool pb_pipelined_eval(const RenderParams& p, int mode) {
   if (p.precise || p.eval_waves > 0 || std::getenv("PB_OLD_EVAL")) return false;
   if (mode == PB_MODE_721) return !wide_records(p);

@@ -172,10 +172,12 @@ def test_het_render_matches_oracle(pb):
         lbvh = ctx.draw(mode=pb.MODE_73HET, cull="lbvh").astype(np.float64)
         fast = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)     # default: relaxed arithmetic
         fast2 = ctx.draw(mode=pb.MODE_73HET, cull="bins")
-        # the same kernel addressing records by their own 64-bit addresses (segment sets beyond 2 GB of records), behind
-        # either binning pass: the same bits
+        # the same estimator addressing records by their own 64-bit addresses (segment sets beyond 2 GB of records), behind
+        # either binning pass, without the residue launch (every item evaluates the pairs it leaves to the exact-order
+        # code) and as the one-pass kernel very large segment sets take: the same bits
         wide = []
-        for env in (dict(PB_TUNE_WIDE="1"), dict(PB_TUNE_WIDE="1", PB_TUNE_FUSED_MAX="0")):
+        for env in (dict(PB_TUNE_WIDE="1"), dict(PB_TUNE_WIDE="1", PB_TUNE_FUSED_MAX="0"), dict(PB_TUNE_NO_RESIDUE="1"),
+                    dict(PB_TUNE_HET1="1"), dict(PB_TUNE_HET1="1", PB_TUNE_WIDE="1")):
             os.environ.update(env)
             try:
                 wide.extend(ctx.draw(mode=pb.MODE_73HET, cull="bins") for _ in range(2))
