@@ -1807,9 +1807,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
     if (lane < take && !(p.debug & 8)) {
       const int e = waiting - take + lane;
       const uint32_t key = fq_key[e];
-      sidx = key >> 6; rl = key & 63u;
+      sidx = (key & 0x7fffffffu) >> 6; rl = key & 63u;
       const float t_mid = fq_val[0][e], y_star = fq_val[1][e], y_err = fq_val[2][e], sin2 = fq_val[3][e];
       const float4* rec = (const float4*)(p.frames + sidx);
+      bool passes = true;
+      if (key & 0x80000000u) {
+        // the segment's gate (HitBoundingBox entry against the ray's surface distance) for the ray this pair belongs to
+        const float4 g0 = rec[5], g1 = rec[6], g2 = rec[7];       // W[2] lo.x lo.y | lo.z hi.xyz | cand.xyz vcap10
+        const float lo[3] = {g0.z, g0.w, g1.x}, hi[3] = {g1.y, g1.z, g1.w}, cand[3] = {g2.x, g2.y, g2.z};
+        Ray rq;
+        rq.dn = v3(rr[3 * 64 + rl], rr[4 * 64 + rl], rr[5 * 64 + rl]);
+        rq.maxd = rr[6 * 64 + rl];
+        passes = pair_721_fast_gate(lo, hi, cand, __builtin_bit_cast(uint32_t, rec[3].w), rq);
+      }
       const float4 a3 = rec[3];                               // oy, len, tb0, qflags
       const float4 b0 = rec[4];                               // W[0], W[1]
       const float2 b1 = ((const float2*)rec)[10];             // W[2]
@@ -1822,8 +1832,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
       const float dy = y_star - h0.y;
       const float beta = __builtin_amdgcn_sqrtf(__builtin_fmaf(dy, dy, h0.x));
       const float edge = HET_FAST_EDGE * h0.w + y_err;
-      const bool ok = (beta >= h0.z + edge) && (beta <= h0.w - edge);
-      defer = !ok && (beta >= h0.z - edge) && (beta <= h0.w + edge);
+      const bool ok = passes && (beta >= h0.z + edge) && (beta <= h0.w - edge);
+      defer = passes && !ok && (beta >= h0.z - edge) && (beta <= h0.w + edge);
       if (ok) {
         const float view_distance = t_mid * len;
         const float beam_extinction = __builtin_fmaf(h1.y, beta - h0.z, h1.x);
@@ -1865,28 +1875,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
   // one survivor: the crossing for every lane's ray; `cur` holds the first half of its record, the gate box comes with the
   // second half, and the first half of the next survivor's record is requested into `nxt`
   auto step = [&](u32x16& cur, u32x16& nxt, uint32_t idx_cur, uint32_t idx_nxt) __attribute__((always_inline)) {
-    u32x16 second;
-    if (WIDE) {
-      smem_load16_second(second, p.frames + idx_cur);
-      smem_load16_first(nxt, p.frames + idx_nxt);
-    } else {
-      smem_load16(second, p.frames, idx_cur * (uint32_t)sizeof(SegFrame) + 64u);
-      smem_load16(nxt, p.frames, idx_nxt * (uint32_t)sizeof(SegFrame));
-    }
+    if (WIDE) smem_load16_first(nxt, p.frames + idx_nxt);
+    else smem_load16(nxt, p.frames, idx_nxt * (uint32_t)sizeof(SegFrame));
     SegHalfA a;
     __builtin_memcpy(&a, &cur, 64);
     float tc_minus, t_mid, y_star, y_err, sin2;
     bool ok, undecided;
     pair_het_fast_geometry_flat(a.Rinv, a.ox2, a.oz2, a.c4, a.oy, a.len, r, ok, undecided, tc_minus, t_mid, y_star, y_err, sin2);
-    smem_wait(second, nxt);
-    SegHalfB b;
-    __builtin_memcpy(&b, &second, 64);
-    if (ok && !pair_721_fast_sure(a.qflags, tc_minus, r.maxd)) ok = pair_721_fast_gate(b.lo, b.hi, b.cand, a.qflags, r);
+    smem_wait(nxt);
+    // a crossing that is not sure to pass the segment's gate (pair_721_fast_sure) has the gate run on it in the second
+    // pass, where every lane holds such a pair: bit 31 of its key
+    const bool gate_due = !pair_721_fast_sure(a.qflags, tc_minus, r.maxd);
     const unsigned long long km = __ballot(ok);
     if (km) {
       if (ok) {
         const int e = waiting + (int)lanes_below(km);
-        fq_key[e] = (idx_cur << 6) | (uint32_t)lane;
+        fq_key[e] = (idx_cur << 6) | (uint32_t)lane | (gate_due ? 0x80000000u : 0u);
         fq_val[0][e] = t_mid; fq_val[1][e] = y_star; fq_val[2][e] = y_err; fq_val[3][e] = sin2;
       }
       waiting += __builtin_popcountll(km);
@@ -2209,7 +2213,7 @@ static bool wide_records(const RenderParams& p) { return (size_t)p.n_seg * sizeo
 // the 23.7 M segments (4.5 GB of records) of the largest configuration, whose frame is mostly the cone, the one-pass
 // kernel is faster (2.85 against 3.43 s).  PB_TUNE_HET1 / PB_TUNE_HET2 force one or the other.
 static bool het_two_pass(const RenderParams& p) {
-  if (std::getenv("PB_TUNE_HET1") || p.n_seg >= (1 << 26)) return false;
+  if (std::getenv("PB_TUNE_HET1") || p.n_seg >= (1 << 25)) return false;     // its queue keys: 25 bits of segment, 6 of ray, 1 flag
   return !wide_records(p) || std::getenv("PB_TUNE_HET2") != nullptr;
 }
 bool pb_pipelined_eval(const RenderParams& p, int mode) {
@@ -2334,8 +2338,6 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
       if (p.grid_z) hipLaunchKernelGGL(view_walk_kernel, dim3(p.tiles_x * p.tiles_y * p.ssaa * p.ssaa), dim3(64), 0, s, p);
       if (p.xcd_run > 0) waves = (waves + 8 * p.xcd_run - 1) / (8 * p.xcd_run) * (8 * p.xcd_run);    // whole runs for every XCD
       const bool wide = wide_records(p) || std::getenv("PB_TUNE_WIDE") != nullptr;
-      // eval_items_het2_kernel (the estimator's second half run on queued pairs, 64 to a wave) packs segment and ray
-      // into 32 bits; PB_TUNE_HET1 selects the one-pass kernel
       const bool two_pass = het_two_pass(p);
       if (pb_residue_frame(p, mode)) {
         // the items hand the pairs they leave to the exact-order code to one more launch; the pixels are written after it
