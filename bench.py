@@ -176,10 +176,11 @@ class Bench:
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev,
                                     timeout=datetime.timedelta(seconds=STALL_SECONDS))
 
-    def watchdog(self, _i=None):
-        """(Re-)armed after every step: STALL_SECONDS without one ends the process with every thread's stack on
-        stderr and exit status 1, instead of holding the whole job in a collective."""
-        if self.exchange:
+    def watchdog(self, i=None):
+        """(Re-)armed as the steps go by (every 16th: arming costs the host several microseconds of a 40-microsecond
+        step): STALL_SECONDS without progress ends the process with every thread's stack on stderr and exit status 1,
+        instead of holding the whole job in a collective."""
+        if self.exchange and (i is None or i % 16 == 0):
             faulthandler.dump_traceback_later(STALL_SECONDS, exit=True)
 
     def close(self):
