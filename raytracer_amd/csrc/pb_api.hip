@@ -249,8 +249,13 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
   const size_t px = (size_t)tiles * 64;      // pixel sums are stored per tile
   bool verified = std::memcmp(key, ws.ws_key, sizeof(unsigned long long) * 6) == 0;
   if (!verified) ws.queue_kept = false;
+  // The item length chosen for a frame geometry is tried first for the next segment set rendered with that geometry (a
+  // stop-motion loop re-casts every frame, and choosing anew costs a second counting pass); it is chosen again where
+  // the new set's lists call for a length more than a quarter away.
+  const bool same_geometry = std::memcmp(key + 1, ws.ws_key + 1, sizeof(unsigned long long) * 5) == 0;
+  bool slice_settled = verified;
   if (ctx->tune_slice <= 0) {
-    if (verified && ws.ws_slice > 0) p.slice = ws.ws_slice;
+    if ((verified || same_geometry) && ws.ws_slice > 0) p.slice = ws.ws_slice;
     else if (!verified) ws.ws_slice = 0;
   }
   int want_bins = ws.ws_bin_cap, want_items = ws.ws_item_cap;
@@ -351,7 +356,8 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     PB_HIP(hipMemcpyAsync(ctx->h_ctrl, ws.d_ctrl, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
     PB_HIP(hipStreamSynchronize(s));
     const uint32_t need_items = ctx->h_ctrl[0], need_bins = ctx->h_ctrl[2];
-    if (ctx->tune_slice <= 0 && ws.ws_slice == 0) {
+    if (ctx->tune_slice <= 0 && !slice_settled) {
+      slice_settled = true;
       // Item length from the mean macro-tile list: a wave walks its item's survivors one L2 round trip after
       // the other, so a frame with short lists (few items, GPU far from full) wants short items, while long
       // lists amortise the per-item work better with longer ones.  Measured: 1052 segments 0.145 -> 0.100 ms at
@@ -374,6 +380,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       else if (mean_list >= 4096) longest *= 3;
       const int shortest = queued ? 64 : 48;
       want = want < shortest ? shortest : (want > longest ? longest : want);
+      if (ws.ws_slice > 0 && ws.ws_slice == p.slice && std::abs(want - p.slice) * 4 <= p.slice) want = p.slice;   // near enough: kept
       ws.ws_slice = want;
       if (want != p.slice) {                 // same capacities, queue rebuilt with the new length
         p.slice = want;
