@@ -293,7 +293,8 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     if ((mode == PB_MODE_73HET || mode == PB_MODE_73) && !p.precise && !ws.fixed) {
       // pairs the relaxed estimator cannot decide wait for a launch of their own, so that no item ends with a
       // nearly empty wave running the exact-order code; an item whose pairs do not fit evaluates them itself
-      const int want = groups * 512 < (1 << 18) ? (1 << 18) : groups * 512;
+      const long long wanted = (long long)groups * 512;
+      const int want = wanted < (1 << 18) ? (1 << 18) : (wanted > (1 << 28) ? (1 << 28) : (int)wanted);
       if (want > ws.ws_residue_cap) {
         if (ws.d_residue) PB_HIP(hipFree(ws.d_residue));
         ws.d_residue = nullptr; ws.ws_residue_cap = 0;
@@ -582,7 +583,7 @@ void pb_destroy(pb_ctx* ctx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {ctx->d_tri_xyz, ctx->d_matrix, ctx->d_tris, ctx->d_segs, ctx->d_frames, ctx->d_capA, ctx->d_capB,
                   ctx->d_het, ctx->d_het_axis, ctx->d_het_fast, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
-                  ctx->d_emit_tmp[1], ctx->ws.d_rays, ctx->ws.d_group_last,
+                  ctx->d_emit_tmp[1], ctx->d_emit_tmp[2], ctx->ws.d_rays, ctx->ws.d_group_last,
                   ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list, ctx->ws.d_blk,
                   ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->ws.d_walk, ctx->ws.d_residue, ctx->lb_pool};
   for (void* p : ptrs) if (p) (void)hipFree(p);

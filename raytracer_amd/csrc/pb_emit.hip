@@ -14,6 +14,8 @@
 
 #include <utility>
 
+#include <cstdlib>
+
 #include "pb_internal.h"
 #include "pb_philox.h"
 #include "pb_geom.h"
@@ -54,7 +56,13 @@ struct EmitParams {
   unsigned int* dropped;      // scattering events dropped because the stack was full
   GridView grid;              // extinction field; used when ctl.heterogeneous
   const pb_beam* sources;     // re-cast pass: the beams to cast again (one per lane instead of a photon)
+  int staged;                 // writing pass without a counting pass before it: every photon writes into EMIT_STAGE slots per
+                              // list of its own in beams_const (= the staging buffer) and leaves its counts; gather_staged_kernel
+                              // moves the beams to their places once the offsets are known
+  unsigned int* overflow;     // staged pass: set when a photon pushed more beams into a list than it has slots for
 };
+constexpr int EMIT_STAGE = 16;                   // slots per photon and list of the staged pass
+constexpr int EMIT_STAGE_MAX_PHOTONS = 1 << 18;  // 2 x 16 x 80 B per photon: 655 MB at most
 
 // CastPhotons.h:1128-1141
 PB_DI V4 find_direction(Rng& rng, V4 origin, V4 centre) {
@@ -93,6 +101,7 @@ struct Frame {
 struct BeamSink {
   const EmitParams* p;
   uint32_t photon, order, n_const, n_scatt, off_const, off_scatt;
+  uint32_t cap;               // beams a list has room for at its offset (staged pass: EMIT_STAGE; else no limit)
   bool scattered_only;        // re-cast pass: pushes into the first list are counted in `order` but not kept
 };
 
@@ -111,8 +120,8 @@ PB_DI void push_beam(BeamSink& sink, int parity, V4 start, V4 end, V4 omega_u, f
     b.flags = (ada ? 1u : 0u) | (absorbed ? 4u : 0u) | (parity ? 8u : 0u);   // scattered is never set (CastPhotons.h:398)
     b.photon = sink.photon;
     b.order = sink.order;
-    if (parity) sink.p->beams_scatt[sink.off_scatt + sink.n_scatt] = b;
-    else sink.p->beams_const[sink.off_const + sink.n_const] = b;
+    if (parity) { if (sink.n_scatt < sink.cap) sink.p->beams_scatt[sink.off_scatt + sink.n_scatt] = b; }
+    else if (sink.n_const < sink.cap) sink.p->beams_const[sink.off_const + sink.n_const] = b;
   }
   sink.order++;
   if (parity) sink.n_scatt++; else sink.n_const++;
@@ -282,8 +291,13 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) 
   rng.k0 = (uint32_t)p.seed; rng.k1 = (uint32_t)(p.seed >> 32);
   BeamSink sink;
   sink.p = &p; sink.photon = (uint32_t)i; sink.order = 0; sink.n_const = 0; sink.n_scatt = 0;
-  sink.off_const = (WRITE && !RECAST) ? p.off_const[i] : 0u;
-  sink.off_scatt = WRITE ? p.off_scatt[i] : 0u;
+  const bool staged = WRITE && p.staged != 0;
+  sink.cap = staged ? (uint32_t)EMIT_STAGE : 0xffffffffu;
+  if (staged) { sink.off_const = (uint32_t)i * 2u * EMIT_STAGE; sink.off_scatt = sink.off_const + EMIT_STAGE; }
+  else {
+    sink.off_const = (WRITE && !RECAST) ? p.off_const[i] : 0u;
+    sink.off_scatt = WRITE ? p.off_scatt[i] : 0u;
+  }
   sink.scattered_only = RECAST;
   if (RECAST) {
     const pb_beam b = p.sources[i];
@@ -294,7 +308,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) 
     f.energy = v3(b.energy[0], b.energy[1], b.energy[2]);
     f.bounce = 0; f.parity = 0; f.stage = 0; f.ada = (b.flags & 1u) != 0;
     cast_beam<WRITE>(p, rng, sink, f, v4(b.omega_u[0], b.omega_u[1], b.omega_u[2], b.omega_u[3]), b.radius);
-    if (!WRITE) { p.cnt_const[i] = 0u; p.cnt_scatt[i] = sink.n_scatt; }
+    if (!WRITE || staged) { p.cnt_const[i] = 0u; p.cnt_scatt[i] = sink.n_scatt; }
+    if (staged && sink.n_scatt > (uint32_t)EMIT_STAGE) atomicOr(p.overflow, 1u);
     return;
   }
 
@@ -322,7 +337,21 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) 
   f.energy = v3(C.light_power[0], C.light_power[1], C.light_power[2]);
   f.bounce = 0; f.parity = 0; f.stage = 0; f.ada = C.adaptive != 0;
   cast_beam<WRITE>(p, rng, sink, f, omega_u, r);
-  if (!WRITE) { p.cnt_const[i] = sink.n_const; p.cnt_scatt[i] = sink.n_scatt; }
+  if (!WRITE || staged) { p.cnt_const[i] = sink.n_const; p.cnt_scatt[i] = sink.n_scatt; }
+  if (staged && (sink.n_const > (uint32_t)EMIT_STAGE || sink.n_scatt > (uint32_t)EMIT_STAGE)) atomicOr(p.overflow, 1u);
+}
+
+// The beams of a staged pass to their places in the two lists: one lane per photon (or re-cast beam).
+__global__ __launch_bounds__(256) void gather_staged_kernel(const pb_beam* __restrict__ stage, const uint32_t* __restrict__ cnt_const,
+                                                           const uint32_t* __restrict__ cnt_scatt, const uint32_t* __restrict__ off_const,
+                                                           const uint32_t* __restrict__ off_scatt, pb_beam* __restrict__ beams_const,
+                                                           pb_beam* __restrict__ beams_scatt, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const pb_beam* mine = stage + (size_t)i * 2 * EMIT_STAGE;
+  const uint32_t nc = cnt_const[i], ns = cnt_scatt[i];
+  for (uint32_t k = 0; k < nc; ++k) beams_const[off_const[i] + k] = mine[k];
+  for (uint32_t k = 0; k < ns; ++k) beams_scatt[off_scatt[i] + k] = mine[EMIT_STAGE + k];
 }
 
 // ---------------------------------------------------------------- segments --
@@ -499,7 +528,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   PB_HIP(hipEventRecord(ctx->ev[6], s));
   // scratch: cnt_const[n] cnt_scatt[n] off_const[n] off_scatt[n] totals[4] dropped[1] root[6] + scan tmp
   const size_t n = (size_t)n_photons;
-  const size_t scan_words = pb_scan_tmp_words(n_photons > 0 ? n_photons : 1);
+  const size_t scan_words = pb_scan_tmp_words(n_photons > 0 ? 2 * n_photons : 1);
   const size_t head = 4 * n + 16 + 6 * ROOT_BOX_BLOCKS;
   uint32_t* tmp_a = nullptr;
   int rc = emit_scratch(ctx, 0, head + scan_words, &tmp_a);
@@ -522,19 +551,37 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   ep.grid.z = ctx->d_grid; ep.grid.side = ctx->grid_side; ep.grid.fast_div = ctx->grid_fast_div;
   ep.sources = old_beams;
   const int blocks = (n_photons + EMIT_THREADS - 1) / EMIT_THREADS;
-  if (n_photons > 0) {
+  // Up to EMIT_STAGE_MAX_PHOTONS photons the beams are cast once, into slots of the photon's own, and moved when the
+  // offsets are known (the photon pass of a small set is one long chain of dependent steps per lane; casting twice,
+  // to count and then to write, doubled it).  A photon that outgrows its slots sends the pass the two-pass way.
+  const bool staged = n_photons > 0 && n_photons <= EMIT_STAGE_MAX_PHOTONS && !std::getenv("PB_TUNE_EMIT_TWICE");
+  pb_beam* stage = nullptr;
+  if (staged) {
+    uint32_t* raw = nullptr;
+    rc = emit_scratch(ctx, 2, (sizeof(pb_beam) * 2 * EMIT_STAGE * n + sizeof(uint32_t) - 1) / sizeof(uint32_t), &raw);
+    if (rc != PB_OK) return rc;
+    stage = (pb_beam*)raw;
+    ep.staged = 1; ep.overflow = totals + 4;
+    ep.beams_const = stage; ep.beams_scatt = stage;
+    if (recast) hipLaunchKernelGGL((emit_kernel<true, true>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+    else hipLaunchKernelGGL((emit_kernel<true, false>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
+  } else if (n_photons > 0) {
     if (recast) hipLaunchKernelGGL((emit_kernel<false, true>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
     else hipLaunchKernelGGL((emit_kernel<false, false>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
   }
   PB_HIP(hipGetLastError());
-  rc = pb_exclusive_scan_u32(cnt_const, off_const, n_photons, totals + 0, scan_tmp, s);
-  if (rc != PB_OK) return rc;
-  rc = pb_exclusive_scan_u32(cnt_scatt, off_scatt, n_photons, totals + 1, scan_tmp, s);
+  // one scan over both count arrays (they are adjacent, and so are the offset arrays): a photon's offset into the
+  // scattered list then already counts the first list before it, whose length is the first scattered offset
+  rc = pb_exclusive_scan_u32(cnt_const, off_const, 2 * n_photons, totals + 1, scan_tmp, s);
   if (rc != PB_OK) return rc;
   uint32_t h_tot[4] = {0, 0, 0, 0};
-  PB_HIP(hipMemcpyAsync(h_tot, totals, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, s));
+  PB_HIP(hipMemcpyAsync(h_tot + 1, totals + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  if (n_photons > 0) PB_HIP(hipMemcpyAsync(h_tot + 0, off_scatt, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  uint32_t h_overflow = 0;
+  if (staged) PB_HIP(hipMemcpyAsync(&h_overflow, totals + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   PB_HIP(hipStreamSynchronize(s));
-  const int nc = recast ? n_photons : (int)h_tot[0], ns = (int)h_tot[1], nb = nc + ns;
+  const int listed_const = (int)h_tot[0];                  // beams the count pass put in the first list
+  const int nc = recast ? n_photons : listed_const, ns = (int)h_tot[1] - listed_const, nb = nc + ns;
 
   // the new list goes into the spare buffer (a re-cast reads the old list while it writes the new one)
   const size_t want_beams = (size_t)(nb > 0 ? nb : 1);
@@ -547,9 +594,13 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   pb_beam* new_beams = ctx->d_beams_spare;
   if (recast && nc > 0)
     PB_HIP(hipMemcpyAsync(new_beams, old_beams, sizeof(pb_beam) * (size_t)nc, hipMemcpyDeviceToDevice, s));
-  ep.beams_const = new_beams; ep.beams_scatt = new_beams + nc;
-  PB_HIP(hipMemsetAsync(totals + 3, 0, sizeof(uint32_t), s));   // the counting pass reported the same drops
-  if (n_photons > 0) {
+  ep.beams_const = new_beams; ep.beams_scatt = new_beams + nc - listed_const;   // off_scatt counts the first list's beams
+  if (staged && !h_overflow) {
+    hipLaunchKernelGGL(gather_staged_kernel, dim3((n_photons + 255) / 256), dim3(256), 0, s, stage, cnt_const, cnt_scatt, off_const,
+                       off_scatt, ep.beams_const, ep.beams_scatt, n_photons);
+  } else if (n_photons > 0) {
+    PB_HIP(hipMemsetAsync(totals + 3, 0, sizeof(uint32_t), s));   // the pass before this one reported the same drops
+    ep.staged = 0;
     if (recast) hipLaunchKernelGGL((emit_kernel<true, true>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
     else hipLaunchKernelGGL((emit_kernel<true, false>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
   }

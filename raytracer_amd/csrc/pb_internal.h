@@ -260,8 +260,8 @@ struct pb_ctx {
   size_t cap_beams = 0;                    // records d_beams can hold
   pb_beam* d_beams_spare = nullptr;        // the other of the two beam buffers: a new list never aliases the old one
   size_t cap_beams_spare = 0;
-  uint32_t* d_emit_tmp[2] = {nullptr, nullptr};   // photon-pass scratch (counts, offsets, scan space), kept between calls
-  size_t emit_tmp_words[2] = {0, 0};
+  uint32_t* d_emit_tmp[3] = {nullptr, nullptr, nullptr};   // photon-pass scratch (counts, offsets, scan space; beam staging), kept between calls
+  size_t emit_tmp_words[3] = {0, 0, 0};
   int n_beams_const = 0, n_beams_scatt = 0;
   // segments
   pb_segment* d_segs = nullptr;

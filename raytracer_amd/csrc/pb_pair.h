@@ -572,12 +572,12 @@ PB_DI void pair_het_fast_geometry_flat(const float Rinv[9], float ox2, float oz2
   const float inv2a = fast_rcp(a + a);
   const float t0 = (-b - sq) * inv2a;
   const float t1 = (-b + sq) * inv2a;
-  const bool ordered = (t0 > 0) & (t1 > t0);
+  const bool ordered = ((int)(t0 > 0) & (int)(t1 > t0)) != 0;
   const float dpy = __builtin_fmaf(Rinv[7], l.z, __builtin_fmaf(Rinv[4], l.y, Rinv[1] * l.x));
   const float y0 = __builtin_fmaf(t0, dpy, oy);
   const float y1 = __builtin_fmaf(t1, dpy, oy);
   const float y_err = 2e-6f * (fabsf(oy) + fabsf(t1 * dpy));
-  const bool in_caps = !((fmaxf(y0, y1) < -y_err) | (fminf(y0, y1) > 1.0f + y_err));
+  const bool in_caps = ((int)(fmaxf(y0, y1) < -y_err) | (int)(fminf(y0, y1) > 1.0f + y_err)) == 0;
   const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);
   const float sy = __builtin_amdgcn_fmed3f(y1, 0.0f, 1.0f);
   const float q = -fast_rcp(dpy);
@@ -588,11 +588,11 @@ PB_DI void pair_het_fast_geometry_flat(const float Rinv[9], float ox2, float oz2
   const float noise = 2.5e-7f * t_mid * fast_rcp(fmaxf(ths - thf, 1e-30f) * a);
   const float edge = fmaxf(HET_FAST_EDGE, noise) * t_mid + y_err * fabsf(q);
   y_err_out = y_err + edge;
-  const bool outside = (t_mid < thf - edge) | (t_mid > ths + edge);
-  const bool near = (t_mid < thf + edge) | (t_mid > ths - edge);
-  const bool base = hit & !end_on & ordered & in_caps & !outside;
-  ok_out = base & !near;
-  defer_out = hit & (end_on | (base & near));
+  const bool outside = ((int)(t_mid < thf - edge) | (int)(t_mid > ths + edge)) != 0;
+  const bool near = ((int)(t_mid < thf + edge) | (int)(t_mid > ths - edge)) != 0;
+  const bool base = ((int)hit & (int)!end_on & (int)ordered & (int)in_caps & (int)!outside) != 0;
+  ok_out = ((int)base & (int)!near) != 0;
+  defer_out = ((int)hit & ((int)end_on | ((int)base & (int)near))) != 0;
   t_mid_out = t_mid;
   y_star_out = __builtin_fmaf(t_mid, dpy, oy);
   sin2_out = a;
