@@ -190,3 +190,30 @@ def test_rotated_camera_and_moved_light(pb):
     assert ref.max() > 0.3 and cnt["valid_hits"] > 20000
     assert (err <= 2e-3 * np.maximum(1.0, np.abs(ref))).all(), err.max()
     assert np.sqrt((err ** 2).mean()) <= 1e-4
+
+
+@pytest.mark.parametrize("het", [False, True])
+def test_one_pass_and_two_pass_emission_give_the_same_lists(pb, het, monkeypatch):
+    """The photon pass casts once into per-photon slots and gathers (the default up to 2^18 photons), or counts, scans
+    and casts again (larger sets, or a photon that outgrows its slots): beams, segments and a re-cast must come out
+    byte for byte the same either way."""
+    kw = dict(photon_number=3000, bounces=3, screen_width=64, screen_height=64)
+    if het:
+        kw.update(heterogeneous=1, one_dimensional=1)
+    got = {}
+    for twice in (False, True):
+        if twice:
+            monkeypatch.setenv("PB_TUNE_EMIT_TWICE", "1")
+        else:
+            monkeypatch.delenv("PB_TUNE_EMIT_TWICE", raising=False)
+        with pb.Context(pb.control_defaults(**kw)) as ctx:
+            ctx.set_scene()
+            if het:
+                ctx.set_grid(*pb.make_grid())
+            counts = ctx.cast_photon_beams()
+            beams, segs, root = ctx.download_beams(), ctx.download_segments(), np.concatenate(ctx.root_box())
+            recounts = ctx.recast_photon_beams(seed=77)
+            got[twice] = (counts, beams.tobytes(), segs.tobytes(), root.tobytes(), recounts, ctx.download_beams().tobytes(),
+                          ctx.download_segments().tobytes())
+    assert got[False][0][0] > 3000 and got[False][4][1] > 0
+    assert got[False] == got[True]
