@@ -262,6 +262,23 @@ class Bench:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         kernel_ms = ev0.elapsed_time(ev1) / steps
+        # The same frames with nothing kept from one to the next: counting pass, queue build, fill, evaluation and
+        # pixel write-out every frame (the list offsets and the item queue are functions of the segment set and the
+        # frame geometry alone, and `value` is measured with them kept from the first frame, as a tree would be).
+        unkept_ms = None
+        if world == 1 and with_extras and not self.exchange:
+            os.environ["PB_TUNE_NO_KEEP"] = "1"
+            try:
+                tiles.run_steps(pipe, frame, render, max(2, warmup // 2))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                tiles.run_steps(pipe, frame, render, max(10, steps // 2))
+                torch.cuda.synchronize()
+                unkept_ms = (time.perf_counter() - t1) / max(10, steps // 2) * 1e3
+            finally:
+                del os.environ["PB_TUNE_NO_KEEP"]
+            tiles.run_steps(pipe, frame, render, 2)      # the kept queue is in place again for what follows
+            torch.cuda.synchronize()
         kt = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
         if self.exchange:
             dist.all_reduce(kt, op=dist.ReduceOp.MAX)
@@ -318,6 +335,11 @@ class Bench:
                     "note": "FP32 vector-ALU bound (no MFMA; the working set is cache-resident, traffic = HBM bytes per frame "
                             "from the FETCH_SIZE / WRITE_SIZE passes of the same profile); achieved = FP32 operations per "
                             "launch / launch time measured here with HIP events on the launch stream"},
+                "schedule_rebuilt_every_frame": None if unkept_ms is None else {
+                    "ms_per_step": unkept_ms, "value": rays / (unkept_ms * 1e-3) / 1e6, "unit": "Mray/s",
+                    "note": "the same frames with the binning count pass and the queue build repeated every frame "
+                            "(five launches instead of two); `value` keeps list offsets and item queue, which depend on "
+                            "the segment set and the frame geometry only, from the first frame of a segment set"},
                 "pair_queries_per_s": rays * n_segs * steps / dt,
                 "frame_ok": frame_ok,
                 "per_ray": {k: cnt[k] / rays for k in ("candidates", "cyl_hits", "valid_hits", "gate_passes")},

@@ -324,7 +324,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       p.blk = ws.d_blk;
     }
     if (ctx->count_on || ctx->time_render) PB_HIP(hipEventRecord(ctx->ev[0], s));
-    if (verified && ws.queue_kept && p.fused_queue && !ctx->count_on && p.n_seg > 0) {
+    if (verified && ws.queue_kept && p.fused_queue && !ctx->count_on && p.n_seg > 0 && !std::getenv("PB_TUNE_NO_KEEP")) {
       // The list offsets and the item queue are functions of the segment set and the frame geometry alone and are in
       // the workspace from the frame that sized it for this key: ray set-up + the fill of the lists, evaluation, pixels.
       p.n_items_host = ws.ws_items_needed;

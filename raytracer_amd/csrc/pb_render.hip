@@ -1008,7 +1008,8 @@ __global__ __launch_bounds__(MBIN_THREADS) void setup_count_kernel(const RenderP
 // segment set and frame geometry): ray set-up beside the one binning pass it needs, the fill.
 __global__ __launch_bounds__(MBIN_THREADS) void setup_fill_kernel(const RenderParams p, int n_macro, int bin_blocks, int groups, int scene_in_lds) {
   extern __shared__ __align__(16) uint32_t bin_lds[];
-  if ((int)blockIdx.x < bin_blocks) { macro_bin_body<true>(p, n_macro, bin_lds, blockIdx.x); return; }
+  if ((int)blockIdx.x < bin_blocks) { if (!(p.debug & 64)) macro_bin_body<true>(p, n_macro, bin_lds, blockIdx.x); return; }
+  if (p.debug & 32) return;
   ray_role(p, bin_lds, (int)blockIdx.x - bin_blocks, groups, scene_in_lds);
 }
 
@@ -1449,6 +1450,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = sum.ng = 0u;
   const SegFrame* frames = p.frames;
   const float extinction = p.extinction_c;
+  if (p.debug & 128) ns = 0;             // timing experiment: no pair loop
+  if (p.debug & 256) return;             // timing experiment: no pair loop, no write-out
   for (int b0 = 0; b0 < ns; b0 += 64) {
     const int nb = (ns - b0) < 64 ? (ns - b0) : 64;
     const int mine = (lane < nb) ? (int)surv[b0 + lane] : 0;

@@ -39,3 +39,6 @@ def test_bench_line_has_the_contract_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mray/s" and "sample" in cb
     assert d["frame_ok"] is True and d["pipelined"]["frames_identical"] is True
+    # the same frames with nothing kept from one frame to the next are reported beside the headline, and are slower
+    unkept = d["schedule_rebuilt_every_frame"]
+    assert unkept["ms_per_step"] > 0 and unkept["value"] > 10 and unkept["unit"] == "Mray/s"

@@ -1,0 +1,7 @@
+#!/bin/bash
+# eval_items_fast_kernel time with parts left out (PB_DEBUG_FLAGS: 128 no pair loop, 256 neither pair loop nor write-out); on the GPU box
+for w in cfg1 cfg2; do for f in 0 128 256; do
+  export PB_DEBUG_FLAGS=$f
+  timeout -k 10 300 python tools/profile_frame.py $w gpurun_out/s4_evexp_$f trace > /dev/null || exit 1
+  echo "$w flags $f: $(grep 'eval_items_fast_kernel<true>' gpurun_out/s4_evexp_$f/${w}_kernel_stats.csv | cut -d, -f1,2,4)"
+done; done
