@@ -250,3 +250,59 @@ def test_integral_73het_per_pair(pb):
             assert abs(val[i] - ref) <= 0.05 * abs(ref) + 1e-6, (i, val[i], ref)
     assert n_valid > 1000 and n_pos > 200
     assert n_close >= 0.999 * n_valid, (n_close, n_valid)
+
+
+@pytest.mark.parametrize("w,h,ssaa", [(100, 52, 2), (37, 23, 3), (264, 8, 1)])
+def test_het_awkward_frames_relaxed_against_exact_order(pb, w, h, ssaa):
+    """Frames whose sides are no multiple of a tile, with sub-samples: the relaxed-arithmetic estimator (two passes,
+    residue launch) against the exact-order frame, a pixel rectangle cut out of the frame against the frame's own
+    pixels, and a repeat."""
+    kw = dict(photon_number=500, bounces=1, screen_width=w, screen_height=h, ssaa=ssaa)
+    with pb.Context(het_control(pb, **kw)) as ctx:
+        ctx.set_scene()
+        ctx.set_grid(*pb.make_grid())
+        ctx.cast_photon_beams()
+        fast = ctx.draw(mode=pb.MODE_73HET, cull="bins")
+        again = ctx.draw(mode=pb.MODE_73HET, cull="bins")
+        x0, y0 = min(9, w - 1), min(3, h - 1)
+        part = ctx.draw(x0, y0, w - x0, h - y0, mode=pb.MODE_73HET, cull="bins")
+        ctx.set_precise(True)
+        exact = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)
+    assert np.array_equal(fast, again) and exact.max() > 0.01
+    assert np.array_equal(part, fast[y0:, x0:])
+    err = np.abs(fast - exact)
+    assert (err <= 2e-3 * np.maximum(1.0, exact)).all(), err.max()
+    assert np.sqrt((err ** 2).mean()) <= 1e-4
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_het_rank_strips_reassemble_to_the_frame(pb, world):
+    """Interleaved strips of the heterogeneous frame (relaxed estimator: walk tables, two passes, residue launch per
+    rank's share) put in image order equal the frame one context renders, bit for bit."""
+    import torch
+    from raytracer_amd import tiles
+    kw = dict(photon_number=800, bounces=2, screen_width=128, screen_height=128)
+    H = W = 128
+    sigma, side = pb.make_grid()
+    with pb.Context(het_control(pb, **kw)) as src:
+        src.set_scene()
+        src.set_grid(sigma, side)
+        src.cast_photon_beams()
+        segs = src.download_segments()
+        lo, hi = src.root_box()
+        full = src.draw(mode=pb.MODE_73HET, cull="bins")
+    stream = torch.cuda.current_stream().cuda_stream
+    first, stride, n_my = tiles.strips_of_rank(H, 0, world)
+    gathered = torch.zeros((world, n_my * 8, W, 3), dtype=torch.float32, device="cuda")
+    for rank in range(world):
+        first, stride, n_my = tiles.strips_of_rank(H, rank, world)
+        with pb.Context(het_control(pb, **kw)) as ctx:
+            ctx.set_scene()
+            ctx.set_grid(sigma, side)
+            ctx.upload_segments(segs, lo, hi)
+            for _ in range(2):          # the sizing frame, then a frame from the kept queue
+                ctx.draw_strips_device(gathered[rank].data_ptr(), first, stride, n_my, mode=pb.MODE_73HET, cull="bins", stream=stream)
+                torch.cuda.synchronize()
+    frame = tiles.assemble(gathered, torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
+    assert full.max() > 0.05
+    assert np.array_equal(frame.cpu().numpy(), full)
