@@ -1400,7 +1400,9 @@ template <bool FINALIZE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_items_fast_kernel(const RenderParams p) {
   __shared__ uint32_t surv[PB_SLICE];
   const int lane = threadIdx.x;
-  const uint32_t produced = p.ctrl[0];
+  // the number of items is the one the host measured when it sized the workspace for this segment set and frame
+  // (the queue build leaves the same number in ctrl[0]): an argument instead of a trip to memory before the first load
+  const uint32_t produced = (uint32_t)p.n_items_host;
   const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
   // Workgroups go round the eight XCDs by their index, and each XCD has an L2 of its own: the items of one tile, which
   // are neighbours in the queue and read the same rays and much the same records, are kept on one XCD by handing out
@@ -1605,7 +1607,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
   __shared__ uint32_t q_seg[HIT_QUEUE], q_ray[HIT_QUEUE];
   __shared__ unsigned long long s_acc[3][64];
   const int lane = threadIdx.x;
-  const uint32_t produced = p.ctrl[0];
+  // the number of items is the one the host measured when it sized the workspace for this segment set and frame
+  // (the queue build leaves the same number in ctrl[0]): an argument instead of a trip to memory before the first load
+  const uint32_t produced = (uint32_t)p.n_items_host;
   const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
   uint32_t c = blockIdx.x;
   if (p.xcd_run > 0) {
@@ -1760,7 +1764,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
   __shared__ unsigned long long s_acc[4][64];             // per ray: red, green, blue, and what all three share
   __shared__ float s_d1len[64];
   const int lane = threadIdx.x;
-  const uint32_t produced = p.ctrl[0];
+  // the number of items is the one the host measured when it sized the workspace for this segment set and frame
+  // (the queue build leaves the same number in ctrl[0]): an argument instead of a trip to memory before the first load
+  const uint32_t produced = (uint32_t)p.n_items_host;
   const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
   uint32_t c = blockIdx.x;
   if (p.xcd_run > 0) {
