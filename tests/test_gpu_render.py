@@ -434,6 +434,21 @@ def test_repeated_frames_of_one_segment_set_are_bit_identical(pb, kw):
         assert np.array_equal(part, first[24:24 + 77, 40:40 + 99])
         assert np.array_equal(ctx.draw(cull="bins"), first)
         assert np.array_equal(ctx.draw(cull="bins"), first)
+        # nothing kept from frame to frame (counting pass and queue build every frame, what bench.py reports as
+        # schedule_rebuilt_every_frame), then kept again
+        import os
+        os.environ["PB_TUNE_NO_KEEP"] = "1"
+        try:
+            for _ in range(3):
+                ctx.draw_device(out.data_ptr(), 0, 0, W, H, cull="bins", stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), first)
+        finally:
+            del os.environ["PB_TUNE_NO_KEEP"]
+        out.fill_(-1.0)
+        ctx.draw_device(out.data_ptr(), 0, 0, W, H, cull="bins", stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), first)
 
 
 @pytest.mark.parametrize("het", [False, True])
