@@ -5,6 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
+#include <chrono>
+#include <deque>
 #include <fstream>
 #include <stdexcept>
 #include <string>
@@ -68,6 +71,7 @@ pb_ctx* context() {
 }
 
 void upload_grid(pb_ctx* ctx, const Grid& grid);
+void remember_scene(const std::vector<float>& tri, const mat4& matrix);
 
 // The helper contexts, one per entry of devices[1..], brought up to date with scene, grid and segment set.
 std::vector<Helper>& helpers() {
@@ -114,6 +118,16 @@ void remember_render_set(const pb_segment* segs, size_t n, const float lo[3], co
 // cone makes rows cost very differently), one host thread per device, each writing its rows of the host image.
 void render_frame(screen* scr, int mode) {
   pb_ctx* ctx = context();
+  {
+    // skeleton.cpp:333-334 (DrawStandard), :370-371 (DrawHet), :417-418 (Draw): the matrix of the frame is made from
+    // the globals when the frame starts; the beams keep the space they were cast in
+    mat4 now;
+    TransformationMatrix(now);
+    if (!g_tri_flat.empty() && std::memcmp(g_matrix, &now.m[0][0], sizeof(g_matrix)) != 0) {
+      check(pb_set_scene(ctx, g_tri_flat.data(), (int)(g_tri_flat.size() / 9), &now.m[0][0]), "pb_set_scene");
+      remember_scene(g_tri_flat, now);
+    }
+  }
   const int w = scr->width, h = scr->height;
   std::vector<float> rgb((size_t)w * h * 3);
   if (devices.size() <= 1) {
@@ -446,6 +460,57 @@ void LoadSegments(const char* path, const mat4& matrix, const std::vector<Triang
   }
 }
 void SaveSegments(const char* path) { check(pb_save_segments(context(), path), "pb_save_segments"); }
+
+// ---------------------------------------------------------------- the keyboard loop, without a window --
+namespace { std::deque<int> g_events; constexpr int QUIT_EVENT = -1; }
+void PushKey(int sdl_key_code) { g_events.push_back(sdl_key_code); }
+void PushQuit() { g_events.push_back(QUIT_EVENT); }
+
+bool UserInput() {
+  const double PI = 3.14159265;                   // Tessendorf.h:4; the sums below are formed in double and rounded to float, as there
+  while (!g_events.empty()) {
+    const int key_code = g_events.front();
+    g_events.pop_front();
+    if (key_code == QUIT_EVENT) return false;
+    switch (key_code) {
+      // Rotation
+      case SDLK_UP: theta.x += PI / 180; break;
+      case SDLK_DOWN: theta.x -= PI / 180; break;
+      case SDLK_LEFT: theta.y += PI / 180; break;
+      case SDLK_RIGHT: theta.y -= PI / 180; break;
+      // Move forward/back/left/right
+      case SDLK_w: camera.z += 0.1; break;
+      case SDLK_s: camera.z -= 0.1; break;
+      case SDLK_a: camera.x -= 0.1; break;
+      case SDLK_d: camera.x += 0.1; break;
+      // Move the light
+      case SDLK_l: light_position.x += 0.1; break;
+      case SDLK_j: light_position.x -= 0.1; break;
+      case SDLK_o: light_position.y -= 0.1; break;
+      case SDLK_u: light_position.y += 0.1; break;
+      case SDLK_k: light_position.z -= 0.1; break;
+      case SDLK_i: light_position.z += 0.1; break;
+      // Reset state
+      case SDLK_r:
+        camera = vec4{0, 0, -3.00f, 1};
+        theta = vec3{0.0f, 0.0f, 0.0f};
+        light_position = vec4{0, -0.5f, -0.7f, 1};
+        break;
+      case SDLK_ESCAPE: return false;
+    }
+  }
+  return true;
+}
+
+bool Update() {
+  using clock = std::chrono::steady_clock;
+  static clock::time_point t = clock::now();       // SDL_GetTicks() at the first call
+  const clock::time_point t2 = clock::now();
+  const float dt = (float)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t).count();
+  t = t2;
+  std::cout << "Render time: " << dt << " ms." << std::endl;
+  return UserInput();
+}
 
 pb_stats Stats() {
   pb_stats s;

@@ -118,6 +118,23 @@ void RunAnalysis();
 void LoadSegments(const char* path, const mat4& matrix, const std::vector<Triangle>& triangles);
 void SaveSegments(const char* path);
 
+// skeleton.cpp:475-486 and :534-610, the loop every run of the reference ends in (`while( Update() ) { Draw...; }`),
+// without SDL: Update prints the time since its last call ("Render time: ... ms.") and returns UserInput(); UserInput
+// applies every queued key press to theta / camera / light_position exactly as the reference's switch does and returns
+// false on SDLK_ESCAPE or a queued quit.  Keys come from PushKey (the SDLK_* values below are SDL2's) instead of a
+// window; an empty queue leaves the state alone and returns true.  As in the reference, Draw* read
+// TransformationMatrix from the globals on every frame (so a camera key moves the walls of the next frame), while the
+// beams stay as cast until the caller casts again (a light key only matters to the next CastPhotonBeams).
+enum : int {
+  SDLK_ESCAPE = 27, SDLK_a = 'a', SDLK_d = 'd', SDLK_i = 'i', SDLK_j = 'j', SDLK_k = 'k', SDLK_l = 'l', SDLK_o = 'o',
+  SDLK_r = 'r', SDLK_s = 's', SDLK_u = 'u', SDLK_w = 'w',
+  SDLK_RIGHT = 0x4000004F, SDLK_LEFT = 0x40000050, SDLK_DOWN = 0x40000051, SDLK_UP = 0x40000052
+};
+void PushKey(int sdl_key_code);     // an SDL_KEYDOWN event for the next UserInput
+void PushQuit();                    // an SDL_QUIT event
+bool UserInput();                   // skeleton.cpp:534-610
+bool Update();                      // skeleton.cpp:475-486
+
 // Counters and device times of the last calls (pb_counters).
 pb_stats Stats();
 // Releases the GPU context (the reference leaks its tree; a long-running host may not want to).

@@ -209,3 +209,45 @@ def test_device_list_errors_are_reported(tmp_path):
     r = subprocess.run([EXE, "100", "0", "64", str(tmp_path / "b.bmp")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=60, env=env)
     assert r.returncode == 1 and "error" in r.stdout
+
+
+def test_keyboard_loop_without_a_window(tmp_path):
+    """skeleton.cpp:226-230, :475-486, :534-610 through the host layer (examples/keys_headless.cpp): Update / UserInput
+    fed from a script of key presses.  A camera key moves the walls of the next frame while the beams stay as cast
+    (DrawStandard makes its matrix from the globals every frame, skeleton.cpp:333-334), `r` restores camera and
+    rotation and sets the light where the reference's reset puts it, a light key shows only after a new photon pass."""
+    import raytracer_amd as pb
+    exe = os.path.join(ROOT, "examples", "keys_headless")
+    assert os.path.exists(exe), "examples/keys_headless is not built (make -C raytracer_amd/csrc)"
+    prefix = str(tmp_path / "k")
+    keys = ["j", "w", "left", "r", "l", "cast"]
+    r = subprocess.run([exe, "600", "128", prefix] + keys, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("Render time:") == len(keys) + 1       # one Update per frame and the one that ends the loop
+    frames = [read_bmp32(f"{prefix}_{k}.bmp") for k in range(len(keys))]
+    # the state the reference's switch leaves: reset, then light.x += 0.1 (float arithmetic through double, as there)
+    assert "camera 0 0 -3 theta 0 0 0 light 0.1 -0.5 -0.7" in r.stdout
+    kw = dict(photon_number=600, screen_width=128, screen_height=128)
+    ctl = pb.control_defaults(**kw)
+    with pb.Context(ctl) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        plain = pb.quantise_argb(ctx.draw(cull="bins"))
+        cam = np.float32(np.float64(np.float32(-3.0)) + 0.1)                       # camera.z += 0.1
+        ctx.set_scene(matrix=pb.transformation_matrix([0.0, 0.0, 0.0], [0.0, 0.0, float(cam), 1.0]))
+        moved = pb.quantise_argb(ctx.draw(cull="bins"))
+        th = np.float32(np.float64(np.float32(0.0)) + 3.14159265 / 180)            # theta.y += PI / 180
+        ctx.set_scene(matrix=pb.transformation_matrix([0.0, float(th), 0.0], [0.0, 0.0, float(cam), 1.0]))
+        turned = pb.quantise_argb(ctx.draw(cull="bins"))
+    assert np.array_equal(frames[0], plain)          # `j` moved the light only: nothing of it shows before a new photon pass
+    assert np.array_equal(frames[1], moved) and not np.array_equal(moved, plain)
+    assert np.array_equal(frames[2], turned) and not np.array_equal(turned, moved)
+    assert np.array_equal(frames[3], plain)          # reset
+    assert np.array_equal(frames[4], plain)          # `l`: the light again
+    # after the new photon pass the beams come from the moved light
+    lp = [float(np.float32(np.float64(np.float32(0.0)) + 0.1)), -0.5, -0.7, 1.0]
+    with pb.Context(pb.control_defaults(light_position=lp, **kw)) as ctx:
+        ctx.set_scene()
+        ctx.cast_photon_beams()
+        relit = pb.quantise_argb(ctx.draw(cull="bins"))
+    assert np.array_equal(frames[5], relit) and not np.array_equal(relit, plain)
