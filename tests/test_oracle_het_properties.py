@@ -99,3 +99,51 @@ def test_field_varying_along_x_shows_b_r_equals_b_l():
         seen_difference += int((np.abs(as_written - bilinear) > 1e-3).sum())
         assert np.abs(got - bilinear)[np.abs(as_written - bilinear) > 1e-3].min(initial=1.0) > 5e-4
     assert seen_difference > 500
+
+
+def _het_set(field, n_photons=250):
+    """An oracle-made heterogeneous segment set over `field` (a side x side array of sigma_t), its root box and controls."""
+    kw = dict(photon_number=n_photons, bounces=1, screen_width=64, screen_height=64, heterogeneous=1, one_dimensional=1)
+    ctl = orc.control_defaults(**kw)
+    o = orc.Oracle(ctl)
+    o.set_grid(field, SIDE)
+    o.cast_photon_beams()
+    o.bound_photon_beams()
+    segs = o.export_segments(tree=False)
+    lo, hi = o.root_box()
+    return kw, ctl, segs, lo, hi
+
+
+def test_integral_73het_in_a_constant_field_is_the_homogeneous_integral_73():
+    """BeamRadiance.h:211-288 against :159-192: where the field equals sigma_t = absorption + scattering everywhere,
+    every sample, every running mean and every interpolated end value is that constant, so Integral_73Het's
+    transmittances and its scattering (beam extinction / sigma_t x sigma_s) are Integral_73's.  The restatement of
+    the heterogeneous branch (which no output of the reference pins) must reduce to the homogeneous one."""
+    base = orc.control_defaults()
+    sigma_t = np.float32(base.absorption_c) + np.float32(base.scattering_c)
+    field = np.full(SIDE * SIDE, sigma_t, np.float32)
+    kw, ctl, segs, lo, hi = _het_set(field)
+    assert len(segs) > 1000 and np.allclose(segs["c_ext"], sigma_t, rtol=1e-6) and np.allclose(segs["e_ext"], sigma_t, rtol=1e-6)
+    tri, _ = orc.load_test_model()
+    args = (orc.tri_xyz(tri), orc.transformation_matrix(), segs, lo, hi, 0, 0, 64, 64)
+    het, c_het = orc.render_segments(ctl, *args, mode=orc.MODE_73HET, grid_sigma=field, side=SIDE)
+    hom_ctl = orc.control_defaults(**dict(kw, heterogeneous=0))
+    hom, c_hom = orc.render_segments(hom_ctl, *args, mode=orc.MODE_73)
+    assert c_het["valid_hits"] == c_hom["valid_hits"] > 1000 and hom.max() > 0.01
+    # equal up to the rounding of a mean of equal samples (sum / n) and of float products taken in another order
+    assert np.abs(het - hom).max() <= 2e-6 * max(1.0, hom.max())
+
+
+def test_integral_73het_is_linear_in_the_beam_energy_and_additive_over_segments():
+    rng = np.random.default_rng(11)
+    field = (0.2 + 0.3 * rng.random(SIDE * SIDE)).astype(np.float32)
+    kw, ctl, segs, lo, hi = _het_set(field, n_photons=150)
+    tri, _ = orc.load_test_model()
+    def frame(s):
+        return orc.render_segments(ctl, orc.tri_xyz(tri), orc.transformation_matrix(), s, lo, hi, 0, 0, 64, 64,
+                                   mode=orc.MODE_73HET, grid_sigma=field, side=SIDE)[0]
+    whole = frame(segs)
+    twice = segs.copy(); twice["energy"] *= 2
+    assert whole.max() > 0.01
+    assert np.abs(frame(twice) - 2 * whole).max() <= 1e-12 * max(1.0, whole.max())
+    assert np.abs(frame(segs[0::2]) + frame(segs[1::2]) - whole).max() <= 1e-9 * max(1.0, whole.max())
