@@ -149,7 +149,7 @@ constexpr int VIEW_WALK_XY = 16;     // table rows per lateral axis: running sum
 constexpr int VIEW_WALK_Z = 8;       // and along z (cells are 1 deep: 7 crossings reach z = 5)
 constexpr int VIEW_WALK_ROWS = 2 * VIEW_WALK_XY + VIEW_WALK_Z;
 constexpr int VIEW_WALK_MAX_SIDE = 30;
-constexpr int VIEW_WALK_PARAMS = 11;                                   // rows after the tables: ViewWalk's members
+constexpr int VIEW_WALK_PARAMS = 16;                                   // rows after the tables: ViewWalk's members, 16 floats per ray
 constexpr int VIEW_WALK_STRIDE = VIEW_WALK_ROWS + VIEW_WALK_PARAMS;    // rows of 64 floats per ray group
 
 struct ViewWalk {
@@ -157,6 +157,8 @@ struct ViewWalk {
   float cap[3];           // crossings of the axis that the walk sampled
   float e0;               // the sample at distance 0
   float t_unsure;         // distance of the first crossing whose order the tabulated walk cannot vouch for
+  float lx, ly;           // the ray's unit direction (x, y) and the length of its once-normalised vec4 direction, kept with
+  float d1_len;           // the walk for the evaluation's second pass (set by view_walk_kernel, not by view_walk_tabulate)
 };
 
 // sigma_t at grid coordinates (px, py) = position - grid_min, read in cell (ix, iy) as DdaWalk::sample reads it.
@@ -226,14 +228,23 @@ PB_DI ViewWalk view_walk_tabulate(const GridView& g, V3 l, float* tab, int lane)
   return w;
 }
 
+// A ray's numbers sit together (four 16-byte accesses per ray): the evaluation's second pass reads them for the ray a
+// queued pair belongs to, not for its own lane.
 PB_DI void view_walk_store(const ViewWalk& w, float* rows, int lane) {
-  for (int k = 0; k < 3; ++k) { rows[k * 64 + lane] = w.t0[k]; rows[(3 + k) * 64 + lane] = w.rate[k]; rows[(6 + k) * 64 + lane] = w.cap[k]; }
-  rows[9 * 64 + lane] = w.e0; rows[10 * 64 + lane] = w.t_unsure;
+  float4* at = (float4*)rows + 4 * lane;
+  at[0] = make_float4(w.t0[0], w.t0[1], w.t0[2], w.e0);
+  at[1] = make_float4(w.rate[0], w.rate[1], w.rate[2], w.t_unsure);
+  at[2] = make_float4(w.cap[0], w.cap[1], w.cap[2], 0.0f);
+  at[3] = make_float4(w.lx, w.ly, w.d1_len, 0.0f);
 }
 PB_DI ViewWalk view_walk_load(const float* rows, int lane) {
+  const float4* at = (const float4*)rows + 4 * lane;
+  const float4 a = at[0], b = at[1], c = at[2], d = at[3];
   ViewWalk w;
-  for (int k = 0; k < 3; ++k) { w.t0[k] = rows[k * 64 + lane]; w.rate[k] = rows[(3 + k) * 64 + lane]; w.cap[k] = rows[(6 + k) * 64 + lane]; }
-  w.e0 = rows[9 * 64 + lane]; w.t_unsure = rows[10 * 64 + lane];
+  w.t0[0] = a.x; w.t0[1] = a.y; w.t0[2] = a.z; w.e0 = a.w;
+  w.rate[0] = b.x; w.rate[1] = b.y; w.rate[2] = b.z; w.t_unsure = b.w;
+  w.cap[0] = c.x; w.cap[1] = c.y; w.cap[2] = c.z;
+  w.lx = d.x; w.ly = d.y; w.d1_len = d.z;
   return w;
 }
 

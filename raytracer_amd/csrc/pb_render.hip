@@ -1596,7 +1596,10 @@ __global__ __launch_bounds__(64) void view_walk_kernel(const RenderParams p) {
   GridView grid;
   grid.z = p.grid_z; grid.side = p.grid_side; grid.fast_div = p.grid_fast_div;
   float* wt = p.walk + (size_t)group * VIEW_WALK_STRIDE * 64;
-  const ViewWalk w = view_walk_tabulate(grid, v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]), wt, lane);
+  const V3 l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+  ViewWalk w = view_walk_tabulate(grid, l, wt, lane);
+  w.lx = l.x; w.ly = l.y;
+  w.d1_len = length3(v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]));
   view_walk_store(w, wt + VIEW_WALK_ROWS * 64, lane);
 }
 
@@ -1762,7 +1765,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
   __shared__ float fq_val[4][FAST_QUEUE];                 // t_mid, y*, the margin on y*, sin^2(theta)
   __shared__ uint32_t q_seg[EXACT_QUEUE], q_ray[EXACT_QUEUE]; // pairs left to the exact-order code
   __shared__ unsigned long long s_acc[4][64];             // per ray: red, green, blue, and what all three share
-  __shared__ float s_d1len[64];
   const int lane = threadIdx.x;
   // the number of items is the one the host measured when it sized the workspace for this segment set and frame
   // (the queue build leaves the same number in ctrl[0]): an argument instead of a trip to memory before the first load
@@ -1791,7 +1793,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
   r.maxd = rr[6 * 64 + lane];
   r.d1 = r.dn;
   r.active = r.maxd >= 0.0f;
-  s_d1len[lane] = length3(v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]));
   int ns = 0;
   for (int base = 0; base < cn; base += 64) {
     const int k = base + lane;
@@ -1886,10 +1887,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
         const float beam_extinction = __builtin_fmaf(h1.y, beta - h0.z, h1.x);
         float view_extinction = p.extinction_c;
         if (grid.z) {
-          const float cut = view_distance * s_d1len[rl];
           const ViewWalk w = view_walk_load(wt + VIEW_WALK_ROWS * 64, (int)rl);
+          const float cut = view_distance * w.d1_len;
           defer = cut >= w.t_unsure;           // the exact-order code evaluates this pair; the term added below is zero
-          view_extinction = view_walk_mean(grid, w, v3(rr[0 * 64 + rl], rr[1 * 64 + rl], 0.0f), cut, wt, (int)rl);
+          view_extinction = view_walk_mean(grid, w, v3(w.lx, w.ly, 0.0f), cut, wt, (int)rl);
         }
         const float depth = __builtin_fmaf(beam_extinction * beta, len, view_extinction * view_distance);
         const float transmitted = __builtin_amdgcn_exp2f(__builtin_fmaf(depth, -1.44269504f, -10.0f));   // times the 2^-10 of the sums
