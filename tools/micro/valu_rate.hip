@@ -7,7 +7,8 @@
 
 #define REP8(x) x x x x x x x x
 template <int KIND>
-__global__ void rate_kernel(float* out, int iters, float seed) {
+__global__ void rate_kernel(float* out, int iters, float seed, int active) {
+  if ((int)(threadIdx.x & 63) >= active) return;    // lanes past `active` leave: the wave runs on with part of EXEC
   float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
   float b0 = seed, b1 = seed + 1, b2 = seed + 2, b3 = seed + 3, b4 = seed + 4, b5 = seed + 5, b6 = seed + 6, b7 = seed + 7;
   double d0 = seed, d1 = seed + 1, d2 = seed + 2, d3 = seed + 3;
@@ -68,7 +69,7 @@ __global__ void rate_kernel(float* out, int iters, float seed) {
 }
 
 template <int KIND>
-void run(const char* name, int instr_per_iter, int cus, double ghz) {
+void run(const char* name, int instr_per_iter, int cus, double ghz, int active = 64) {
   float* out;
   hipMalloc(&out, sizeof(float) * 256 * 8 * 4 * 64 * 4);
   const int iters = 4000;
@@ -76,9 +77,9 @@ void run(const char* name, int instr_per_iter, int cus, double ghz) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int blocks = cus, threads = 64 * 4 * wps;      // one block per CU, wps waves on each of its 4 SIMDs
-    hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(threads), 0, 0, out, 10, 1.0f);
+    hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(threads), 0, 0, out, 10, 1.0f, active);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0f);
+    hipLaunchKernelGGL(rate_kernel<KIND>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0f, active);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -107,5 +108,12 @@ int main() {
   run<2>("v_max_f32", 64, p.multiProcessorCount, ghz);
   run<3>("v_fma_f64", 64, p.multiProcessorCount, ghz);
   run<4>("v_rcp_f32", 64, p.multiProcessorCount, ghz);
+  // part of EXEC: does a wave64 instruction cost less when only its low 32 (16) lanes are on?
+  run<6>("v_fmac_f32, 32 lanes", 64, p.multiProcessorCount, ghz, 32);
+  run<6>("v_fmac_f32, 16 lanes", 64, p.multiProcessorCount, ghz, 16);
+  run<7>("v_fmac (SGPR), 32 lanes", 64, p.multiProcessorCount, ghz, 32);
+  run<2>("v_max_f32, 32 lanes", 64, p.multiProcessorCount, ghz, 32);
+  run<10>("v_cmp+cndmask, 32 lanes", 64, p.multiProcessorCount, ghz, 32);
+  run<4>("v_rcp_f32, 32 lanes", 64, p.multiProcessorCount, ghz, 32);
   return 0;
 }
