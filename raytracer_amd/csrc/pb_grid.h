@@ -237,15 +237,17 @@ PB_DI void view_walk_store(const ViewWalk& w, float* rows, int lane) {
   at[2] = make_float4(w.cap[0], w.cap[1], w.cap[2], 0.0f);
   at[3] = make_float4(w.lx, w.ly, w.d1_len, 0.0f);
 }
-PB_DI ViewWalk view_walk_load(const float* rows, int lane) {
-  const float4* at = (const float4*)rows + 4 * lane;
-  const float4 a = at[0], b = at[1], c = at[2], d = at[3];
+PB_DI ViewWalk view_walk_unpack(float4 a, float4 b, float4 c, float4 d) {
   ViewWalk w;
   w.t0[0] = a.x; w.t0[1] = a.y; w.t0[2] = a.z; w.e0 = a.w;
   w.rate[0] = b.x; w.rate[1] = b.y; w.rate[2] = b.z; w.t_unsure = b.w;
   w.cap[0] = c.x; w.cap[1] = c.y; w.cap[2] = c.z;
   w.lx = d.x; w.ly = d.y; w.d1_len = d.z;
   return w;
+}
+PB_DI ViewWalk view_walk_load(const float* rows, int lane) {
+  const float4* at = (const float4*)rows + 4 * lane;
+  return view_walk_unpack(at[0], at[1], at[2], at[3]);
 }
 
 // Extinction3D's mean for the ray cut at distance s (the walk's t_max).
@@ -258,12 +260,22 @@ PB_DI float view_walk_mean(const GridView& g, const ViewWalk& w, V3 l, float s, 
     const float c = floorf((s - w.t0[k]) * w.rate[k]) + 1.0f;       // crossing j lies at t0 + j / rate
     n[k] = __builtin_amdgcn_fmed3f(c, 0.0f, w.cap[k]);              // NaN (an axis the ray runs along): none
   }
-  // the closing sample: at s, in the cell the walk stands in
+  // the closing sample: at s, in the cell the walk stands in (grid_sigma_in_cell, with its load issued beside the others)
   const float fx0 = floorf(1.0f / cell), fy0 = fx0;
   const float ix = fx0 + ((l.x < 0) ? -n[0] : n[0]), iy = fy0 + ((l.y < 0) ? -n[1] : n[1]);
-  const float e_end = grid_sigma_in_cell(g, 1.0f + l.x * s, 1.0f + l.y * s, ix, iy, cell, rcell);
-  const float sum = w.e0 + tab[(int)n[0] * 64 + lane] + tab[(VIEW_WALK_XY + (int)n[1]) * 64 + lane] +
-                    tab[(2 * VIEW_WALK_XY + (int)n[2]) * 64 + lane] + e_end;
+  const float cx = __builtin_amdgcn_fmed3f(ix, 0.0f, res), cy = __builtin_amdgcn_fmed3f(iy, 0.0f, res);
+  float4 c = g.cells()[(int)cy * g.side + (int)cx];
+  float t0 = tab[(int)n[0] * 64 + lane], t1 = tab[(VIEW_WALK_XY + (int)n[1]) * 64 + lane],
+        t2 = tab[(2 * VIEW_WALK_XY + (int)n[2]) * 64 + lane];
+  // one wait for the four loads: left to itself the compiler requests each where the sum needs it, four trips to memory
+  // one after the other
+  asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
+  const float px = 1.0f + l.x * s, py = 1.0f + l.y * s;
+  const float prop_x = fabsf(px - cell * cx) * rcell, prop_y = fabsf(py - cell * cy) * rcell;
+  const float left = c.x + ((c.y - c.x) * prop_y);
+  const float right = c.z + ((c.w - c.z) * prop_y);
+  const float e_end = fmaxf(left + ((right - left) * prop_x), 0.0f);
+  const float sum = w.e0 + t0 + t1 + t2 + e_end;
   return sum * __builtin_amdgcn_rcpf(n[0] + n[1] + n[2] + 2.0f);
 }
 
