@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on one box: the library built from other sources (raytracer_amd/lib/libphoton_beams_old.so, put there by hand) against
 # the current one, alternating, on the workloads named (default cfg3)
-#   bash tools/ab_cfg3.sh [cfg1 cfg2 ...]
+#   bash tools/ab_libs.sh [cfg1 cfg2 ...]
 L=raytracer_amd/lib
 W=${@:-cfg3}
 cp $L/libphoton_beams.so /tmp/new.so

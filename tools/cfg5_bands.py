@@ -18,7 +18,7 @@ import raytracer_amd as pb  # noqa: E402
 
 photons = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-band = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+band = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 lattice = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 precise = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 bar = 1e-5 if precise else 2e-3
