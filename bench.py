@@ -263,8 +263,8 @@ class Bench:
         dt = float(t.item())
         kernel_ms = ev0.elapsed_time(ev1) / steps
         # The same frames with nothing kept from one to the next: counting pass, queue build, fill, evaluation and
-        # pixel write-out every frame (the list offsets and the item queue are functions of the segment set and the
-        # frame geometry alone, and `value` is measured with them kept from the first frame, as a tree would be).
+        # pixel write-out every frame (the lists, their offsets and the item queue are functions of the segment set and
+        # the frame geometry alone, and `value` is measured with them kept from the first frame, as a tree would be).
         unkept_ms = None
         if world == 1 and with_extras and not self.exchange:
             os.environ["PB_TUNE_NO_KEEP"] = "1"
@@ -337,9 +337,10 @@ class Bench:
                             "launch / launch time measured here with HIP events on the launch stream"},
                 "schedule_rebuilt_every_frame": None if unkept_ms is None else {
                     "ms_per_step": unkept_ms, "value": rays / (unkept_ms * 1e-3) / 1e6, "unit": "Mray/s",
-                    "note": "the same frames with the binning count pass and the queue build repeated every frame "
-                            "(five launches instead of two); `value` keeps list offsets and item queue, which depend on "
-                            "the segment set and the frame geometry only, from the first frame of a segment set"},
+                    "note": "the same frames with both binning passes and the queue build repeated every frame "
+                            "(five launches instead of two); `value` keeps the lists, their offsets and the item queue, "
+                            "which depend on the segment set and the frame geometry only, from the first frame of a "
+                            "segment set (as a tree would be kept)"},
                 "pair_queries_per_s": rays * n_segs * steps / dt,
                 "frame_ok": frame_ok,
                 "per_ray": {k: cnt[k] / rays for k in ("candidates", "cyl_hits", "valid_hits", "gate_passes")},

@@ -325,14 +325,15 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     }
     if (ctx->count_on || ctx->time_render) PB_HIP(hipEventRecord(ctx->ev[0], s));
     if (verified && ws.queue_kept && p.fused_queue && !ctx->count_on && p.n_seg > 0 && !std::getenv("PB_TUNE_NO_KEEP")) {
-      // The list offsets and the item queue are functions of the segment set and the frame geometry alone and are in
-      // the workspace from the frame that sized it for this key: ray set-up + the fill of the lists, evaluation, pixels.
+      // The lists, their offsets and the item queue are functions of the segment set and the frame geometry alone and are
+      // in the workspace from the frame that sized it for this key (as a tree would be kept): ray set-up, evaluation,
+      // pixels.  PB_TUNE_REFILL fills the lists again every frame (the binning pass beside the ray set-up).
       p.n_items_host = ws.ws_items_needed;
       // runs of 64 queue items per XCD: a tile's items share an L2 (cfg2: 91 -> 60 MB fetched by the evaluation, same
       // time; 512^2 / 1000 photons 0.0447 -> 0.0420 ms); frames with very many items lose 2 % to it and deal singly
       if (p.xcd_run < 0) p.xcd_run = ws.ws_items_needed <= (1 << 17) ? 64 : 0;
       p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !pb_residue_frame(p, mode) && !std::getenv("PB_SEPARATE_FINALIZE")) ? 1 : 0;
-      rc = pb_launch_fast_frame(p, mode, s);
+      rc = pb_launch_fast_frame(p, mode, !std::getenv("PB_TUNE_REFILL"), s);
       if (rc != PB_OK) return rc;
       if (ctx->count_on || ctx->time_render) { PB_HIP(hipEventRecord(ctx->ev[1], s)); ctx->ev_valid[0] = true; }
       return PB_OK;

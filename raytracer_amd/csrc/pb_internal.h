@@ -359,7 +359,7 @@ PB_HDI int pb_macro_count(const RenderParams& p) {
   return ((p.tiles_x + p.macro_w - 1) / p.macro_w) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
 }
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s);
-int pb_launch_fast_frame(const RenderParams& p, int mode, hipStream_t s);
+int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, hipStream_t s);
 bool pb_residue_frame(const RenderParams& p, int mode);   // the frame's evaluation hands pairs to a residue launch (pixels written after it)
 
 #endif

@@ -2449,14 +2449,16 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
 
 // A frame whose list offsets (sub_off), item queue (items, ctrl[0]) and per-tile list lengths are in the workspace
 // from the frame that sized it for the same segment set and frame geometry: three launches.
-int pb_launch_fast_frame(const RenderParams& p, int mode, hipStream_t s) {
+int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, hipStream_t s) {
   const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
   if (groups <= 0) return PB_OK;
   const int n_macro = pb_macro_count(p);
-  const int bin_blocks = pb_mbin_blocks(p.n_seg);
+  // the lists themselves are a function of the segment set and the frame geometry too: where an earlier frame of both
+  // left them in the workspace, no block bins
+  const int bin_blocks = lists_in_place ? 0 : pb_mbin_blocks(p.n_seg);
   const int ray_blocks = (groups + MBIN_THREADS / 64 - 1) / (MBIN_THREADS / 64);
   const int scene_in_lds = p.n_tri <= SCENE_LDS_MAX_TRI ? 1 : 0;
-  const size_t lds = std::max(pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)128 * p.n_tri : (size_t)0);
+  const size_t lds = std::max(lists_in_place ? (size_t)0 : pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)128 * p.n_tri : (size_t)0);
   hipLaunchKernelGGL(setup_fill_kernel, dim3(bin_blocks + ray_blocks), dim3(MBIN_THREADS), lds, s,
                      p, n_macro, bin_blocks, groups, scene_in_lds);
   return launch_eval_finalize(p, mode, false, s);

@@ -409,9 +409,9 @@ def test_short_view_rays(pb):
 @pytest.mark.parametrize("kw", [dict(screen_width=512, screen_height=512, photon_number=1000, bounces=0),
                                 dict(screen_width=200, screen_height=136, photon_number=600, bounces=2, ssaa=2)])
 def test_repeated_frames_of_one_segment_set_are_bit_identical(pb, kw):
-    """The first binned frame of a segment set sizes the workspace and leaves list offsets and the item queue in
-    it; the frames after it are three launches (ray set-up + list fill, evaluation whose last item per tile writes
-    the pixels).  Every such frame must equal the first one and the ordered scan path's radiance."""
+    """The first binned frame of a segment set sizes the workspace and leaves the lists, their offsets and the item
+    queue in it; the frames after it are two launches (ray set-up, evaluation whose last item per tile writes the
+    pixels).  Every such frame must equal the first one and the ordered scan path's radiance."""
     import torch
     with pb.Context(pb.control_defaults(**kw)) as ctx:
         ctx.set_scene()
@@ -449,6 +449,25 @@ def test_repeated_frames_of_one_segment_set_are_bit_identical(pb, kw):
         ctx.draw_device(out.data_ptr(), 0, 0, W, H, cull="bins", stream=stream)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), first)
+        # the lists filled again every frame beside the ray set-up (PB_TUNE_REFILL), then kept again
+        os.environ["PB_TUNE_REFILL"] = "1"
+        try:
+            for _ in range(2):
+                out.fill_(-1.0)
+                ctx.draw_device(out.data_ptr(), 0, 0, W, H, cull="bins", stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), first)
+        finally:
+            del os.environ["PB_TUNE_REFILL"]
+        # a new segment set in the same context and geometry: nothing of the old lists may survive
+        ctx.cast_photon_beams(seed=7)
+        other = ctx.draw(cull="bins")
+        assert not np.array_equal(other, first)
+        again = ctx.draw(cull="bins")                 # lists kept from the frame before
+        assert np.array_equal(again, other)
+        scan2 = ctx.draw(cull="scan")
+        assert np.abs(scan2 - other).max() <= 1e-6 * max(1.0, float(scan2.max()))
+        assert np.array_equal(ctx.draw(cull="bins"), other)     # after a frame of another cull mode on the same workspace
 
 
 @pytest.mark.parametrize("het", [False, True])
