@@ -67,13 +67,13 @@ def library_path():
 
 
 def source_stamp():
-    """sha256 (first 16 hex digits) over the kernel sources in raytracer_amd/csrc, in name order: names the
-    build that a committed profile was measured on."""
+    """sha256 (first 16 hex digits) over the kernel sources in raytracer_amd/csrc and the Makefile that holds their
+    compiler flags, in name order: names the build that a committed profile was measured on."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(_HERE, "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
             h.update(name.encode())
             with open(os.path.join(src, name), "rb") as f:
                 h.update(f.read())
