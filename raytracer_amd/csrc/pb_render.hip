@@ -1481,7 +1481,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   PairSums sum;
   sum.ai[0] = sum.ai[1] = sum.ai[2] = sum.ag = 0ull; sum.nc = sum.ng = 0u;
   const SegFrame* frames = p.frames;
-  const float extinction = p.extinction_c;
+  // kept in a vector register: the pair loop's SGPRs are taken by the record buffers (as a scalar it was spilled to a
+  // VGPR lane and read back with v_readlane for every valid pair), and operands from vector registers issue faster
+  float extinction = p.extinction_c;
+  asm volatile("" : "+v"(extinction));
   if (p.debug & 128) ns = 0;             // timing experiment: no pair loop
   if (p.debug & 256) return;             // timing experiment: no pair loop, no write-out
   for (int b0 = 0; b0 < ns; b0 += 64) {
