@@ -61,6 +61,29 @@ def test_noalloc_is_shared_between_contexts_and_estimators():
             assert a.max() > 0 and np.array_equal(a, b)
 
 
+def test_noalloc_contexts_of_one_geometry_do_not_inherit_each_others_lists():
+    """Two contexts with the same screen, rectangle and mode, whose segment sets carry the same version number, take
+    turns on the shared workspace: what one left there (lists, offsets, item queue) must never serve the other."""
+    import torch
+    kw = dict(screen_width=256, screen_height=256, photon_number=800, bounces=1)
+    with pb.Context(pb.control_defaults(**kw), device=0) as one, pb.Context(pb.control_defaults(**kw), device=0) as two:
+        one.set_scene(); one.cast_photon_beams(seed=1)
+        two.set_scene(); two.cast_photon_beams(seed=2)
+        ref = {}
+        for name, ctx in (("one", one), ("two", two)):
+            a, b = _both(ctx, torch, 0, 0, 256, 256)
+            assert a.max() > 0 and np.array_equal(a, b)
+            ref[name] = a
+        assert not np.array_equal(ref["one"], ref["two"])
+        stream = torch.cuda.current_stream().cuda_stream
+        out = torch.zeros((256, 256, 3), dtype=torch.float32, device="cuda")
+        for name, ctx in (("one", one), ("one", one), ("two", two), ("two", two), ("one", one), ("two", two)):
+            out.fill_(-1.0)
+            ctx.draw_noalloc_device(out.data_ptr(), 0, 0, 256, 256, stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), ref[name]), name
+
+
 def test_noalloc_refuses_frames_beyond_its_maxima():
     import torch
     with pb.Context(pb.control_defaults(screen_width=1024, screen_height=1024, photon_number=200), device=0) as ctx:
