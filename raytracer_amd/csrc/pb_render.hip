@@ -1019,16 +1019,17 @@ constexpr int ITEM_LANES = 64;
 // read one triangle at a time through the scalar unit, a wave paid a dependent trip to L2 for every triangle its
 // tile can see.
 constexpr int SCENE_LDS_MAX_TRI = 256;
+template <int THREADS = MBIN_THREADS>
 PB_DI void ray_role(const RenderParams& p, uint32_t* lds, int ray_block, int groups, int scene_in_lds) {
   struct Box4 { float x, y, z, w; };
   typedef __attribute__((address_space(3))) float LdsFloat;
   typedef __attribute__((address_space(3))) Box4 LdsBox4;
   typedef __attribute__((address_space(3))) TriPrep LdsTriPrep;
-  const int group = ray_block * (MBIN_THREADS / 64) + (int)(threadIdx.x >> 6);
+  const int group = ray_block * (THREADS / 64) + (int)(threadIdx.x >> 6);
   if (scene_in_lds) {
     LdsFloat* dst = (LdsFloat*)lds;
     const float* src = (const float*)p.tris;            // n_tri TriPrep records (16 floats), screen boxes (4), screen edges (12)
-    for (int i = threadIdx.x; i < p.n_tri * 32; i += MBIN_THREADS) dst[i] = src[i];
+    for (int i = threadIdx.x; i < p.n_tri * 32; i += THREADS) dst[i] = src[i];
     __syncthreads();
     if (group < groups)
       ray_setup_body<false>(p, group, threadIdx.x & 63, (const LdsTriPrep*)lds, (const LdsBox4*)lds + 4 * p.n_tri,
@@ -1050,6 +1051,13 @@ __global__ __launch_bounds__(MBIN_THREADS) void setup_fill_kernel(const RenderPa
   if ((int)blockIdx.x < bin_blocks) { if (!(p.debug & 64)) macro_bin_body<true>(p, n_macro, bin_lds, blockIdx.x); return; }
   if (p.debug & 32) return;
   ray_role(p, bin_lds, (int)blockIdx.x - bin_blocks, groups, scene_in_lds);
+}
+
+// Ray set-up alone, for frames whose lists are in place.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void setup_rays_kernel(const RenderParams p, int groups, int scene_in_lds) {
+  extern __shared__ __align__(16) uint32_t bin_lds[];
+  ray_role<THREADS>(p, bin_lds, (int)blockIdx.x, groups, scene_in_lds);
 }
 
 __global__ __launch_bounds__(MBIN_THREADS) void fill_items_kernel(const RenderParams p, int n_macro, int bin_blocks, int n_tiles) {
@@ -2462,6 +2470,16 @@ int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, h
   const int ray_blocks = (groups + MBIN_THREADS / 64 - 1) / (MBIN_THREADS / 64);
   const int scene_in_lds = p.n_tri <= SCENE_LDS_MAX_TRI ? 1 : 0;
   const size_t lds = std::max(lists_in_place ? (size_t)0 : pb_mbin_lds_bytes(n_macro), scene_in_lds ? (size_t)128 * p.n_tri : (size_t)0);
+  if (lists_in_place) {
+    // ray set-up alone: blocks of eight waves (512^2, 1052 segments: 0.0392 ms a frame with one wave to a block, 0.0386
+    // with two, 0.0380 with four, 0.0375 with eight, 0.0378 with sixteen; a block stages the scene in LDS once)
+    int waves = 8;
+    if (const char* e = std::getenv("PB_TUNE_RAYWAVES")) waves = std::atoi(e);
+    if (waves == 4) hipLaunchKernelGGL(setup_rays_kernel<256>, dim3((groups + 3) / 4), dim3(256), lds, s, p, groups, scene_in_lds);
+    else if (waves == 16) hipLaunchKernelGGL(setup_rays_kernel<1024>, dim3((groups + 15) / 16), dim3(1024), lds, s, p, groups, scene_in_lds);
+    else hipLaunchKernelGGL(setup_rays_kernel<512>, dim3((groups + 7) / 8), dim3(512), lds, s, p, groups, scene_in_lds);
+    return launch_eval_finalize(p, mode, false, s);
+  }
   hipLaunchKernelGGL(setup_fill_kernel, dim3(bin_blocks + ray_blocks), dim3(MBIN_THREADS), lds, s,
                      p, n_macro, bin_blocks, groups, scene_in_lds);
   return launch_eval_finalize(p, mode, false, s);
