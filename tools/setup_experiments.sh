@@ -1,5 +1,7 @@
 #!/bin/bash
-# setup_fill_kernel time with one of its two roles left out (PB_DEBUG_FLAGS: 32 no ray set-up, 64 no binning); on the GPU box
+# setup_fill_kernel time with one of its two roles left out (PB_DEBUG_FLAGS: 32 no ray set-up, 64 no binning); on the GPU box.
+# PB_TUNE_REFILL: the kernel with both roles runs every frame (frames otherwise keep their lists and only set up rays).
+export PB_TUNE_REFILL=1
 for w in cfg1 cfg2; do for f in 0 32 64 96; do
   export PB_DEBUG_FLAGS=$f
   timeout -k 10 300 python tools/profile_frame.py $w gpurun_out/s4_setexp_$f trace > /dev/null || exit 1
