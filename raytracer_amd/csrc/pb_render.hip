@@ -1787,15 +1787,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 // 64 are waiting every lane takes one - whatever ray it belongs to - fetches what it needs of the segment's records with
 // vector loads, evaluates the rest and adds its term to that ray's sums in LDS (fixed point: the order does not matter).
 // The rays' walk tables stay in global memory (three look-ups per queued pair, served by the caches; in LDS they were
-// 10 KB a wave and held the kernel to three waves per SIMD).
+// 10 KB a wave and held the kernel to three waves per SIMD).  With items of at most HET2_SLICE candidates and one word
+// per pair of the exact-order queue a wave needs 7.5 KB of LDS and 95 VGPRs: five waves per SIMD (512^2, 236 629
+// segments: 0.845 -> 0.769 ms a frame against four).
+constexpr int HET2_SLICE = 256;       // candidates of an item of this kernel (het_two_pass): with the queues below, 7.5 KB of LDS a wave
 constexpr int FAST_QUEUE = 192;       // up to 63 waiting + two survivors' worth of lanes between two looks at the queue
 constexpr int EXACT_QUEUE = 192;      // likewise: 63 + two survivors, or 63 + what one drain of the fast queue hands over
 template <bool FINALIZE, bool WIDE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void eval_items_het2_kernel(const RenderParams p) {
-  __shared__ uint32_t surv[PB_SLICE];
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void eval_items_het2_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[HET2_SLICE];
   __shared__ uint32_t fq_key[FAST_QUEUE];                 // segment * 64 + ray (lane) of a pair whose crossing holds its closest approach
   __shared__ float fq_val[4][FAST_QUEUE];                 // t_mid, y*, the margin on y*, sin^2(theta)
-  __shared__ uint32_t q_seg[EXACT_QUEUE], q_ray[EXACT_QUEUE]; // pairs left to the exact-order code
+  __shared__ uint32_t q_pair[EXACT_QUEUE];                // pairs left to the exact-order code: segment * 64 + ray
   __shared__ unsigned long long s_acc[4][64];             // per ray: red, green, blue, and what all three share
   const int lane = threadIdx.x;
   // the number of items is the one the host measured when it sized the workspace for this segment set and frame
@@ -1834,17 +1837,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
   int pending = 0, waiting = 0;          // entries of the exact-order queue, of the fast queue
   auto push_exact = [&](unsigned long long mask, uint32_t sidx, uint32_t ray) __attribute__((always_inline)) {
-    if ((mask >> lane) & 1ull) {
-      const int e = pending + (int)lanes_below(mask);
-      q_seg[e] = sidx; q_ray[e] = ray;
-    }
+    if ((mask >> lane) & 1ull) q_pair[pending + (int)lanes_below(mask)] = (sidx << 6) | ray;
     pending += __builtin_popcountll(mask);
   };
   auto drain_exact = [&](int take) __attribute__((always_inline)) {
     __syncthreads();
     if (lane < take && !(p.debug & 16)) {
-      const int e = pending - take + lane;
-      const uint32_t sidx = q_seg[e], rl = q_ray[e];
+      const uint32_t pair = q_pair[pending - take + lane];
+      const uint32_t sidx = pair >> 6, rl = pair & 63u;
       Ray rq;
       rq.l = v3(rr[0 * 64 + rl], rr[1 * 64 + rl], rr[2 * 64 + rl]);
       rq.dn = v3(rr[3 * 64 + rl], rr[4 * 64 + rl], rr[5 * 64 + rl]);
@@ -1991,7 +1991,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 5))) void
         __syncthreads();
         uint2* dst = p.residue + PB_RESIDUE_HEAD + (size_t)q * cap;
         if (lane < pending && at + (uint32_t)lane < cap)
-          dst[at + lane] = fits ? make_uint2(q_seg[lane], ((uint32_t)group << 6) | q_ray[lane]) : make_uint2(0xffffffffu, 0u);
+          dst[at + lane] = fits ? make_uint2(q_pair[lane] >> 6, ((uint32_t)group << 6) | (q_pair[lane] & 63u)) : make_uint2(0xffffffffu, 0u);
         if (fits) { pending = 0; continue; }
       }
       if (pending >= 64 || (flushing && waiting == 0 && pending > 0)) { drain_exact(pending < 64 ? pending : 64); continue; }
@@ -2278,6 +2278,7 @@ static bool wide_records(const RenderParams& p) { return (size_t)p.n_seg * sizeo
 // kernel is faster (2.85 against 3.43 s).  PB_TUNE_HET1 / PB_TUNE_HET2 force one or the other.
 static bool het_two_pass(const RenderParams& p) {
   if (std::getenv("PB_TUNE_HET1") || p.n_seg >= (1 << 25)) return false;     // its queue keys: 25 bits of segment, 6 of ray, 1 flag
+  if (p.slice > HET2_SLICE) return false;                                      // its survivor list in LDS
   return !wide_records(p) || std::getenv("PB_TUNE_HET2") != nullptr;
 }
 bool pb_pipelined_eval(const RenderParams& p, int mode) {
