@@ -275,6 +275,29 @@ def test_het_awkward_frames_relaxed_against_exact_order(pb, w, h, ssaa):
     assert np.sqrt((err ** 2).mean()) <= 1e-4
 
 
+@pytest.mark.parametrize("item_length", [64, 192, 384, 512])
+def test_het_frame_does_not_depend_on_the_item_length(pb, item_length, monkeypatch):
+    """Items of at most 256 candidates go to the two-pass kernel, longer ones to the one-pass kernel (its survivor list
+    in LDS has room for 512): whatever length a context is created with (PB_TUNE_SLICE), the frame is the same, bit
+    for bit."""
+    kw = dict(photon_number=1500, bounces=2, screen_width=128, screen_height=128)
+
+    def frame():
+        with pb.Context(het_control(pb, **kw)) as ctx:
+            ctx.set_scene()
+            ctx.set_grid(*pb.make_grid())
+            ctx.cast_photon_beams()
+            a = ctx.draw(mode=pb.MODE_73HET, cull="bins")
+            b = ctx.draw(mode=pb.MODE_73HET, cull="bins")
+            assert np.array_equal(a, b)
+            return a
+
+    ref = frame()
+    assert ref.max() > 0.01
+    monkeypatch.setenv("PB_TUNE_SLICE", str(item_length))
+    assert np.array_equal(frame(), ref)
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_het_rank_strips_reassemble_to_the_frame(pb, world):
     """Interleaved strips of the heterogeneous frame (relaxed estimator: walk tables, two passes, residue launch per
