@@ -1415,6 +1415,7 @@ int orc_tree_stats(orc_ctx* c, int* n_nodes, int* n_leaves, int* max_depth) {
   *n_nodes = (int)c->o.nodes.size(); *n_leaves = leaves; *max_depth = md;
   return 0;
 }
+int orc_lost_segments(orc_ctx* c) { return (int)c->o.lost_segments.size(); }   // CastPhotons.h:84, :1065-1077
 void orc_root_box(orc_ctx* c, float lo[3], float hi[3]) {
   const AABB& b = c->o.root_aabb;
   lo[0] = b.min.x; lo[1] = b.min.y; lo[2] = b.max.z;

@@ -322,6 +322,9 @@ class Oracle:
         self.L.orc_tree_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"nodes": a.value, "leaves": b.value, "max_depth": c.value}
 
+    def lost_segments(self):
+        return int(self.L.orc_lost_segments(self.h))
+
     def root_box(self):
         lo = np.zeros(3, np.float32); hi = np.zeros(3, np.float32)
         self.L.orc_root_box(self.h, _fp(lo), _fp(hi))
