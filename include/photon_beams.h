@@ -246,20 +246,26 @@ int pb_render_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, int use_lbv
 int pb_render_strips_d(pb_ctx* ctx, int first_strip, int strip_stride, int n_strips, int mode,
                        int use_lbvh, float* d_rgb_out, void* stream);
 
-/* pb_render_d through the screen-space bins (use_lbvh = 2) for callers that cannot allocate: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  It calls no
+/* pb_render_d through the screen-space bins (use_lbvh = 2) for callers that cannot allocate: tight serving loops,
+ * harnesses that forbid hipMalloc, code under HIP graph capture (there only the frames after the first of a given
+ * segment set, rectangle and mode: the first one reads two counters back and waits for them on `stream`, which
+ * capture does not allow - render it once before capturing).  It has no counterpart in the reference.  It calls no
  * hipMalloc, hipFree or other allocating routine: everything the frame needs besides its inputs (the context's
  * prepared segment set and scene) and its output lives in one file-scope device array of PB_NOALLOC_SCRATCH_BYTES
  * that every GPU the library runs on holds from the first pb_create on it until the process ends.  Frames beyond the
  * maxima below are refused with PB_ERR_CAPACITY and a message naming the limit; the result equals pb_render_d's bit
  * for bit (PB_MODE_73HET: pb_render_d's under pb_set_precise(ctx, 1) - the array has no room for the per-ray walk
- * tables of the relaxed-arithmetic estimator, so this entry point always runs the exact-order one).  All contexts of a GPU share that array and it keeps the last call's contents (the call clears what it
- * needs zeroed), so calls that overlap in time on one GPU - other streams, other threads - race: issue them one
+ * tables of the relaxed-arithmetic estimator, so this entry point always runs the exact-order one; PB_MODE_73 runs the
+ * relaxed estimator with its undecided pairs evaluated inside the items instead of in a launch of their own, which
+ * gives pb_render_d's bits).  All contexts of a GPU share that array and it keeps the last call's contents (the call
+ * clears what it needs zeroed), so calls that overlap in time on one GPU - other streams, other threads - race: issue them one
  * after the other.  The first frame of a given (segment set, rectangle, mode) waits once on `stream` to read two
  * counters back (how many list entries and evaluation items the frame has); later frames of it do not. */
 #define PB_NOALLOC_MAX_GROUPS 4096          /* 8x8-pixel tiles x SSAA^2 of the rectangle: 512x512 at SSAA 1     */
 #define PB_NOALLOC_MAX_LIST_ENTRIES 1048576 /* (64x64-pixel macro tile, segment) incidences of the frame        */
 #define PB_NOALLOC_MAX_ITEMS 131072         /* evaluation items (tile x slice of its macro tile's list)         */
+#define PB_NOALLOC_MAX_QUEUE_SLOTS 8192     /* 64 per 64x64-pixel macro tile the rectangle touches: 128 macro     *
+                                             * tiles, which only a very wide and thin rectangle exceeds           */
 #define PB_NOALLOC_SCRATCH_BYTES (28u << 20) /* the array: 28 MiB per GPU                                        */
 int pb_render_noalloc_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, float* d_rgb_out, void* stream);
 

@@ -44,7 +44,8 @@ void host_gate_setup(const float lo[3], const float hi[3], GateBox& g) {
 // its own copy at its own address until the process ends), laid out once per device by static_workspace_init.
 // In host code `scratch` is only a handle for hipGetSymbolAddress; kernels and memsets get the address it returns.
 // ---------------------------------------------------------------------------------------------------------
-constexpr size_t NOALLOC_SLOTS = 2 * (size_t)PB_NOALLOC_MAX_GROUPS;     // queue slots (macro tiles are padded to 64 tiles)
+constexpr size_t NOALLOC_SLOTS = PB_NOALLOC_MAX_QUEUE_SLOTS;
+static_assert(NOALLOC_SLOTS == 2 * (size_t)PB_NOALLOC_MAX_GROUPS, "the static workspace is laid out for two slots per ray group");     // queue slots (macro tiles are padded to 64 tiles)
 constexpr size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 constexpr size_t SCRATCH_CTRL = 0;
 constexpr size_t SCRATCH_RAYS = SCRATCH_CTRL + 256;
@@ -133,7 +134,37 @@ int default_mode(const pb_ctx* ctx) {
 
 }  // namespace
 
+void pb_note_reader(pb_ctx* ctx, hipStream_t s) {
+  for (int i = 0; i < ctx->n_reader_streams; ++i) if (ctx->reader_streams[i] == s) return;
+  if (ctx->n_reader_streams < 8) ctx->reader_streams[ctx->n_reader_streams++] = s;
+  else ctx->readers_overflow = true;
+}
+
+int pb_wait_for_readers(pb_ctx* ctx, hipStream_t writer, bool host_waits) {
+  bool whole_device = ctx->readers_overflow;
+  for (int i = 0; i < ctx->n_reader_streams && !whole_device; ++i) {
+    hipStream_t r = ctx->reader_streams[i];
+    if (r == writer) continue;          // stream order does it
+    // a stream the caller has destroyed since: its work has been waited for or abandoned; the device-wide wait below
+    // covers either case
+    if (hipEventRecord(ctx->ev_readers, r) != hipSuccess) { (void)hipGetLastError(); whole_device = true; break; }
+    PB_HIP(hipStreamWaitEvent(writer, ctx->ev_readers, 0));
+  }
+  if (whole_device) PB_HIP(hipDeviceSynchronize());
+  if (whole_device || host_waits) {
+    // nothing noted is still of interest: either it has finished, or the caller's host wait on `writer` covers it
+    const bool keep_writer = !whole_device;
+    ctx->n_reader_streams = 0; ctx->readers_overflow = false;
+    if (keep_writer) {
+      // frames on the writer's own stream are ordered with this call but not with a later writer on another stream
+      ctx->reader_streams[ctx->n_reader_streams++] = writer;
+    }
+  }
+  return PB_OK;
+}
+
 int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s) {
+  ctx->prepare_stream = s;
   PB_HIP(hipEventRecord(ctx->ev[2], s));
   int rc = pb_launch_prepare_segments(ctx->d_segs, ctx->n_seg, mode, ctx->ctl.one_dimensional, ctx->ctl.scattering_c,
                                       ctx->ctl.absorption_c + ctx->ctl.scattering_c, ctx->d_frames, ctx->d_capA, ctx->d_capB, ctx->d_het,
@@ -248,11 +279,18 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
   const int groups = tiles * p.ssaa * p.ssaa;
   const size_t px = (size_t)tiles * 64;      // pixel sums are stored per tile
   bool verified = std::memcmp(key, ws.ws_key, sizeof(unsigned long long) * 6) == 0;
-  if (!verified) ws.queue_kept = false;
   // The item length chosen for a frame geometry is tried first for the next segment set rendered with that geometry (a
   // stop-motion loop re-casts every frame, and choosing anew costs a second counting pass); it is chosen again where
   // the new set's lists call for a length more than a quarter away.
   const bool same_geometry = std::memcmp(key + 1, ws.ws_key + 1, sizeof(unsigned long long) * 5) == 0;
+  if (!verified) {
+    // From here on this frame's passes overwrite the workspace, and they can still fail part-way (a fixed workspace
+    // learns that a frame does not fit only after the counting pass has run): what the workspace held for the old
+    // key is gone either way, so the key goes first and comes back only where a frame has been sized completely.
+    ws.queue_kept = false;
+    std::memset(ws.ws_key, 0, sizeof(ws.ws_key));
+    ws.ws_items_needed = 0;
+  }
   bool slice_settled = verified;
   if (ctx->tune_slice <= 0) {
     if ((verified || same_geometry) && ws.ws_slice > 0) p.slice = ws.ws_slice;
@@ -430,9 +468,16 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
     pb_set_error("pb_render: pb_build_lbvh has not been called for this segment set"); return PB_ERR_STATE;
   }
   if (ctx->frame_mode != mode) {
-    int rc = pb_prepare_frames(ctx, mode, s);
+    // the records are rewritten for the other estimator: frames of the old one may still be running elsewhere
+    int rc = pb_wait_for_readers(ctx, s, false);
     if (rc != PB_OK) return rc;
+    rc = pb_prepare_frames(ctx, mode, s);
+    if (rc != PB_OK) return rc;
+  } else if (ctx->ev_valid[1] && ctx->prepare_stream != s) {
+    // records prepared by a call queued on another stream and not waited for (pb_upload_segments_d)
+    PB_HIP(hipStreamWaitEvent(s, ctx->ev[3], 0));
   }
+  pb_note_reader(ctx, s);
   RenderParams p;
   std::memset(&p, 0, sizeof(p));
   p.tris = ctx->d_tris; p.n_tri = ctx->n_tri; p.tri_box = (const float4*)(ctx->d_tris + ctx->n_tri);
@@ -484,6 +529,7 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
                                      (unsigned long long)mode};
   if (use_lbvh == 2) return render_binned(ctx, ws, p, mode, key, s);
   bool verified = std::memcmp(key, ws.ws_key, sizeof(key)) == 0;
+  if (!verified) { ws.queue_kept = false; std::memset(ws.ws_key, 0, sizeof(ws.ws_key)); ws.ws_items_needed = 0; }   // as in render_binned
   int want_chunks = ws.ws_chunks;
   if (!verified && want_chunks < groups * 2 + 1024) want_chunks = groups * 2 + 1024;
   for (int attempt = 0; attempt < 4; ++attempt) {
@@ -562,6 +608,7 @@ int pb_create(const pb_control* control, int device, pb_ctx** out) {
     PB_HIP(hipSetDevice(device));
     PB_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) PB_HIP(hipEventCreate(&ctx->ev[i]));
+    PB_HIP(hipEventCreateWithFlags(&ctx->ev_readers, hipEventDisableTiming));
     PB_HIP(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * PB_CNT_N));
     PB_HIP(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N));
     PB_HIP(hipMalloc(&ctx->d_matrix, sizeof(float) * 16));
@@ -590,6 +637,7 @@ void pb_destroy(pb_ctx* ctx) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->ev_readers) (void)hipEventDestroy(ctx->ev_readers);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -690,6 +738,8 @@ static int upload_common(pb_ctx* ctx, const pb_segment* src, bool src_on_device,
   int rc = ensure_device(ctx);
   if (rc != PB_OK) return rc;
   rc = pb_ensure_segment_capacity(ctx, n);
+  if (rc != PB_OK) return rc;
+  rc = pb_wait_for_readers(ctx, s, false);      // frames still reading the old records, on whatever stream
   if (rc != PB_OK) return rc;
   if (n > 0)
     PB_HIP(hipMemcpyAsync(ctx->d_segs, src, sizeof(pb_segment) * (size_t)n,

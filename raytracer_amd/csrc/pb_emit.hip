@@ -525,6 +525,11 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   pb_beam* old_beams = recast ? ctx->d_beams : nullptr;
   if (ctx->ctl.heterogeneous && !ctx->d_grid) { pb_set_error("pb_emit_beams: HETEROGENEOUS needs pb_set_grid first"); return PB_ERR_STATE; }
   hipStream_t s = ctx->stream;
+  {
+    // the pass rewrites the segment records in place; frames of the old set may still be running on the caller's streams
+    const int rc = pb_wait_for_readers(ctx, s, true);
+    if (rc != PB_OK) return rc;
+  }
   PB_HIP(hipEventRecord(ctx->ev[6], s));
   // scratch: cnt_const[n] cnt_scatt[n] off_const[n] off_scatt[n] totals[4] dropped[1] root[6] + scan tmp
   const size_t n = (size_t)n_photons;

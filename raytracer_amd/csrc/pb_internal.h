@@ -249,6 +249,16 @@ struct pb_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};   // pairs: 0,1 render; 2,3 prepare; 4,5 build; 6,7 emit
   bool ev_valid[4] = {false, false, false, false};
+  // Ordering between calls that are queued on different streams and not waited for.  Frames read the segment
+  // records, the scene, the grid and the LBVH on the stream the caller names; the calls that rewrite those buffers run
+  // on a stream of their own choosing (upload) or on the context's (photon pass, LBVH build, grid, scene).  A frame
+  // costs nothing for this: it only notes its stream here.  A writer records ev_readers on every noted stream when it
+  // starts - which covers every frame queued there before - and makes its own stream wait for it.
+  hipStream_t reader_streams[8] = {};
+  int n_reader_streams = 0;
+  bool readers_overflow = false;        // more than eight distinct streams: writers wait for the whole device
+  hipEvent_t ev_readers = nullptr;      // hipEventDisableTiming
+  hipStream_t prepare_stream = nullptr; // stream of the last pb_prepare_frames (ev[3] marks its end)
   // scene
   float* d_tri_xyz = nullptr;
   float* d_matrix = nullptr;
@@ -313,6 +323,10 @@ struct pb_ctx {
 };
 
 int pb_ensure_segment_capacity(pb_ctx* ctx, int n);
+// A call about to overwrite what frames read, on stream `writer`: `writer` waits for every frame queued so far.
+// host_waits: the call ends with a host wait on `writer`, after which no noted frame is still running.
+int pb_wait_for_readers(pb_ctx* ctx, hipStream_t writer, bool host_waits);
+void pb_note_reader(pb_ctx* ctx, hipStream_t s);
 int pb_prepare_frames(pb_ctx* ctx, int mode, hipStream_t s);
 int pb_default_mode(const pb_ctx* ctx);
 int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast);

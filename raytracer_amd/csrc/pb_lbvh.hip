@@ -379,10 +379,18 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // traversal and pb_download_lbvh read, then the scratch of the build.  It grows (free + allocate, which waits for the
 // device) only when a segment set exceeds the capacity; otherwise a build allocates nothing and returns as soon as
 // its kernels are queued on the context's stream.  ctx->ev[5] marks the end of the last build: calls that read the
-// tree on another stream wait for it there.
+// tree on another stream wait for it there.  The build itself waits, on the device, for the preparation of the segment
+// set it reads and for the frames that still read the tree it replaces (pb_wait_for_readers).
 int pb_lbvh_build(pb_ctx* ctx) {
   const int n = ctx->n_seg;
   hipStream_t s = ctx->stream;
+  // The build reads the capsules pb_prepare_frames wrote - on the caller's stream after pb_upload_segments_d, which does
+  // not wait - and overwrites the tree a frame queued earlier on another stream may still be traversing.
+  if (ctx->ev_valid[1] && ctx->prepare_stream != s) PB_HIP(hipStreamWaitEvent(s, ctx->ev[3], 0));
+  {
+    const int rc = pb_wait_for_readers(ctx, s, false);
+    if (rc != PB_OK) return rc;
+  }
   PB_HIP(hipEventRecord(ctx->ev[4], s));
   if (n < 2) {   // nothing to build: the renderer scans the (at most one) segment
     ctx->lb_n = n; ctx->lb_version = ctx->segs_version;

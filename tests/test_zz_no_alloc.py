@@ -84,6 +84,39 @@ def test_noalloc_contexts_of_one_geometry_do_not_inherit_each_others_lists():
             assert np.array_equal(out.cpu().numpy(), ref[name]), name
 
 
+def test_noalloc_one_dimensional_estimator_equals_pb_render_d():
+    """PB_MODE_73 (Integral_73, BeamRadiance.h:112-209): the static workspace has no queues for the pairs the relaxed
+    estimator leaves to the exact-order code, so the items evaluate them themselves; the frame is pb_render_d's."""
+    import torch
+    kw = dict(screen_width=256, screen_height=192, photon_number=1500, bounces=1, one_dimensional=1)
+    with pb.Context(pb.control_defaults(**kw), device=0) as ctx:
+        ctx.set_scene(); ctx.cast_photon_beams()
+        for rect in ((0, 0, 256, 192), (16, 8, 101, 77)):
+            a, b = _both(ctx, torch, *rect, mode=pb.MODE_73)
+            assert a.max() > 0 and np.isfinite(a).all()
+            assert np.array_equal(a, b), rect
+
+
+def test_noalloc_frame_refused_after_sizing_does_not_poison_the_next():
+    """A frame whose lists outgrow the static workspace is refused only after its counting pass has run there.  The
+    frame rendered before it (same context, same segment set, a window that fits) must then be sized anew, not taken
+    for verified with the refused frame's leftovers."""
+    import torch
+    kw = dict(screen_width=512, screen_height=512, photon_number=200000, bounces=0)
+    with pb.Context(pb.control_defaults(**kw), device=0) as ctx:
+        ctx.set_scene(); ctx.cast_photon_beams()
+        small = (192, 192, 128, 128)
+        a, b = _both(ctx, torch, *small)
+        assert a.max() > 0 and np.array_equal(a, b)
+        out = torch.zeros((512, 512, 3), dtype=torch.float32, device="cuda")
+        with pytest.raises(pb.PhotonBeamsError) as e:
+            ctx.draw_noalloc_device(out.data_ptr(), 0, 0, 512, 512)
+        assert "(-5)" in str(e.value) and ("list entries" in str(e.value) or "evaluation items" in str(e.value)), str(e.value)
+        torch.cuda.synchronize()
+        a2, b2 = _both(ctx, torch, *small)
+        assert np.array_equal(a2, a) and np.array_equal(b2, a)
+
+
 def test_noalloc_refuses_frames_beyond_its_maxima():
     import torch
     with pb.Context(pb.control_defaults(screen_width=1024, screen_height=1024, photon_number=200), device=0) as ctx:
