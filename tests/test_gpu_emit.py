@@ -18,8 +18,8 @@ def pb():
     return pb
 
 
-def oracle_pass(n_photons, bounces, seed=42):
-    c = orc.control_defaults(photon_number=n_photons, bounces=bounces, seed=seed)
+def oracle_pass(n_photons, bounces, seed=42, **switches):
+    c = orc.control_defaults(photon_number=n_photons, bounces=bounces, seed=seed, **switches)
     o = orc.Oracle(c)
     o.cast_photon_beams(rng_kind=1)
     o.bound_photon_beams()
@@ -28,10 +28,41 @@ def oracle_pass(n_photons, bounces, seed=42):
 
 @pytest.mark.parametrize("n_photons,bounces", [(1000, 0), (3000, 3)])
 def test_emission_matches_oracle(pb, n_photons, bounces):
-    o = oracle_pass(n_photons, bounces)
+    compare_pass_with_oracle(pb, n_photons, bounces)
+
+
+# The Control.h switches of the photon pass that no BASELINE configuration turns: SCATTER false (Control.h:14,
+# CastPhotons.h:419: no beam ever scatters in the medium), SHORT_BEAMS (CastPhotons.h:463: a beam that scatters stops
+# there and its continuation does not bounce), FIXED_RADIUS / RADIUS (CastPhotons.h:338-343: every beam the same radius
+# instead of a draw), ABSORBED > 0 (CastPhotons.h:498: a beam is absorbed at the surface with that probability and then
+# does not bounce).  The medium is made thicker where a switch only matters for beams that scatter (not so thick that
+# a photon nests more scattering events than the device keeps per photon: the pass then fails with a message).
+@pytest.mark.parametrize("switches", [
+    dict(scatter=0, scattering_c=0.1, absorption_c=0.1),
+    dict(short_beams=1, scattering_c=0.1, absorption_c=0.1),
+    dict(fixed_radius=1, radius=0.0125),
+    dict(absorbed=0.3),
+    dict(absorbed=0.3, short_beams=1, fixed_radius=1, radius=0.02, scattering_c=0.1),
+], ids=["scatter_off", "short_beams", "fixed_radius", "absorbed", "all_together"])
+def test_photon_pass_switches_match_oracle(pb, switches):
+    gb, base = compare_pass_with_oracle(pb, 3000, 3, **switches)
+    # and every switch does change the pass
+    plain = oracle_pass(3000, 3, **{k: v for k, v in switches.items() if k in ("scattering_c", "absorption_c")})
+    assert plain.beam_counts() != base.beam_counts() or not np.array_equal(plain.beams()["radius"], gb["radius"])
+    if switches.get("fixed_radius"):
+        assert (gb["radius"] == np.float32(switches["radius"])).all()
+    if switches.get("scatter") == 0:
+        assert ((gb["flags"] & 8) == 0).sum() > 0 and plain.beam_counts()[1] > 0
+    if switches.get("absorbed"):
+        frac = ((gb["flags"] & 4) != 0).mean()
+        assert 0.15 < frac < 0.45, frac
+
+
+def compare_pass_with_oracle(pb, n_photons, bounces, **switches):
+    o = oracle_pass(n_photons, bounces, **switches)
     ob = o.beams()
     oseg = o.export_segments(tree=False)
-    with pb.Context(pb.control_defaults(photon_number=n_photons, bounces=bounces)) as ctx:
+    with pb.Context(pb.control_defaults(photon_number=n_photons, bounces=bounces, **switches)) as ctx:
         ctx.set_scene()
         nb, ns = ctx.cast_photon_beams()
         gb = ctx.download_beams()
@@ -70,6 +101,7 @@ def test_emission_matches_oracle(pb, n_photons, bounces):
     assert (np.linalg.norm(gt["end"] - gt["start"], axis=1) < 1e-5).all()
     olo, ohi = o.root_box()
     np.testing.assert_allclose(glo, olo, atol=2e-5); np.testing.assert_allclose(ghi, ohi, atol=2e-5)
+    return gb, o
 
 
 def test_emission_is_launch_independent_and_seeded(pb):
