@@ -439,21 +439,37 @@ PB_DI float mul_zero_wins(float a, float b) {
 // dwords of its record) and the ray: 0 = no cylinder hit, 1 = nothing to integrate, 2 = a valid crossing whose
 // entry distance is tc_minus and whose integral (times 2^log2_scale, folded into the exponential at no cost) is
 // `value`, still to be passed by the segment's gate.
-PB_DI int pair_721_fast_geometry(const float Rinv[9], float ox2, float oz2, float c4, float oy, float len, float tb0, const Ray& r,
-                                 float extinction, float log2_scale, float& tc_minus_out, float& value) {
-  const V3 l = r.l;
+// The crossing's quadratic (the part every (ray, survivor) pair runs): returns the discriminant, negative = no hit.
+PB_DI float pair_721_fast_quadratic(const float Rinv[9], float ox2, float oz2, float c4, V3 l, float& a_out, float& b_out) {
   const float dpx = __builtin_fmaf(Rinv[6], l.z, __builtin_fmaf(Rinv[3], l.y, Rinv[0] * l.x));
   const float dpz = __builtin_fmaf(Rinv[8], l.z, __builtin_fmaf(Rinv[5], l.y, Rinv[2] * l.x));
   const float a = __builtin_fmaf(dpx, dpx, dpz * dpz);
   const float b = __builtin_fmaf(ox2, dpx, oz2 * dpz);
-  const float b24ac = __builtin_fmaf(b, b, -(a * c4));
+  a_out = a; b_out = b;
+  return __builtin_fmaf(b, b, -(a * c4));
+}
+
+// What follows the quadratic for a pair whose discriminant is not negative: ry = the middle row of R_inv (Rinv[1],
+// Rinv[4], Rinv[7]).  1 = nothing to integrate, 2 = a valid crossing (see pair_721_fast_geometry).
+PB_DI int pair_721_fast_crossing(float a, float b, float b24ac, V3 ry, float oy, float len, float tb0, V3 l,
+                                 float extinction, float log2_scale, float& tc_minus_out, float& value);
+
+PB_DI int pair_721_fast_geometry(const float Rinv[9], float ox2, float oz2, float c4, float oy, float len, float tb0, const Ray& r,
+                                 float extinction, float log2_scale, float& tc_minus_out, float& value) {
+  float a, b;
+  const float b24ac = pair_721_fast_quadratic(Rinv, ox2, oz2, c4, r.l, a, b);
   if (b24ac < 0) return 0;
+  return pair_721_fast_crossing(a, b, b24ac, v3(Rinv[1], Rinv[4], Rinv[7]), oy, len, tb0, r.l, extinction, log2_scale, tc_minus_out, value);
+}
+
+PB_DI int pair_721_fast_crossing(float a, float b, float b24ac, V3 ry, float oy, float len, float tb0, V3 l,
+                                 float extinction, float log2_scale, float& tc_minus_out, float& value) {
   const float sq = __builtin_amdgcn_sqrtf(b24ac);
   const float inv2a = fast_rcp(a + a);
   const float t0 = (-b - sq) * inv2a;     // a > 0: already ordered, t0 <= t1
   const float t1 = (-b + sq) * inv2a;
   if (!((t0 > 0) && (t1 > t0))) return 1;
-  const float dpy = __builtin_fmaf(Rinv[7], l.z, __builtin_fmaf(Rinv[4], l.y, Rinv[1] * l.x));
+  const float dpy = __builtin_fmaf(ry.z, l.z, __builtin_fmaf(ry.y, l.y, ry.x * l.x));
   const float y0 = __builtin_fmaf(t0, dpy, oy);
   const float y1 = __builtin_fmaf(t1, dpy, oy);
   const float y_low = fminf(y0, y1);

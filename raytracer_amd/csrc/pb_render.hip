@@ -1331,7 +1331,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // its own waits, which only makes those waits stricter.  The survivors' indices sit in a VGPR (lane j: survivor j)
 // and are picked with v_readlane, so the loop touches LDS once per 64 candidates.  The tile's pyramid planes come
 // from row 7 of its ray block (ray_setup_body) instead of being normalised again by every item.
-// Tried and dropped: the survivors' records copied to LDS and read back as vector operands (a vector instruction
+// Tried and dropped: the pair loop cut behind the discriminant, the crossing lanes (half of them on average) compacted
+// through an LDS queue and the rest of the pair evaluated 64 pairs to a wave, each lane fetching its segment's fields with
+// 16-byte loads and its ray with ds_bpermute (the shape eval_items_het2_kernel has): frames bit for bit the same, and
+// 0.0367 -> 0.0506 ms at 1000 photons, 0.177 -> 0.279 ms at 10 000, 3.15 -> 6.02 ms at 100 000 / 1024^2.  With one pair in two
+// crossing there is a drain every two survivors, and a drain's five per-lane gathers of 64 different records cost the
+// vector memory pipe more cycles than the half-empty lanes cost the vector ALU.
+// Also: the survivors' records copied to LDS and read back as vector operands (a vector instruction
 // with a scalar-register source issues in 4.3 cycles against 2.6 on vector registers alone, tools/micro/valu_rate.hip):
 // 0.245 ms against 0.223 ms at 10 000 photons, 0.277 ms with the next record requested a candidate ahead (80 registers).
 struct SegHalfA { float Rinv[9]; float ox2, oz2, c4, oy, len, tb0; uint32_t qflags; };      // SegFrame dwords 0..15
