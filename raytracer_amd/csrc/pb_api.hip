@@ -263,6 +263,86 @@ int ensure_blk(FrameWorkspace& ws, size_t need) {
   return PB_OK;
 }
 
+// The kept queue of a (segment set, frame geometry): every item's candidates are tested against its tile's pyramid once
+// (refine_items_kernel: count, prefix sum, write) and the survivors, one contiguous run per tile, are cut into items of
+// equal length (regroup_items_kernel).  Two read-backs (survivors in all, items in all): this runs once per segment set
+// and geometry, in a frame that has waited for the device already.  The rays' tile planes and group_last of this
+// frame geometry must be in the workspace.  p.items / p.tile_items still describe the queue as it was built.
+int build_survivor_lists(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, int slots, hipStream_t s) {
+  ws.surv_ready = false;
+  const int n_old = p.n_items_host;
+  if (n_old <= 0 || ws.fixed) return PB_OK;
+  const size_t scan_words = pb_scan_tmp_words(n_old > slots ? n_old : slots);
+  const size_t words = 2 * (size_t)n_old + 1 + 2 * (size_t)slots + scan_words + 8;
+  if (words > ws.ws_surv_words) {
+    if (ws.d_surv_cnt) PB_HIP(hipFree(ws.d_surv_cnt));
+    ws.d_surv_cnt = nullptr; ws.ws_surv_words = 0;
+    const size_t cap = words + words / 4;
+    PB_HIP(hipMalloc(&ws.d_surv_cnt, sizeof(uint32_t) * cap));
+    ws.ws_surv_words = cap;
+  }
+  p.surv_cnt = ws.d_surv_cnt;
+  uint32_t* off = ws.d_surv_cnt + n_old;                 // n_old + 1 entries
+  uint32_t* regroup_cnt = off + n_old + 1;
+  uint32_t* regroup_off = regroup_cnt + slots;
+  uint32_t* scan_tmp = regroup_off + slots;
+  uint32_t* d_items_total = scan_tmp + scan_words;
+  int rc = pb_launch_refine_items(p, false, s);
+  if (rc != PB_OK) return rc;
+  rc = pb_exclusive_scan_u32(p.surv_cnt, off, n_old, off + n_old, scan_tmp, s);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipMemcpyAsync(ctx->h_ctrl, off + n_old, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  PB_HIP(hipStreamSynchronize(s));
+  const size_t total = ctx->h_ctrl[0];
+  // Item length.  A frame with little work in all is bound by its longest item (a wave walks its survivors one after
+  // the other while the rest of the chip idles), a frame with much work by what every item pays before and after its
+  // pair loop (rays, sums): about three items per wave the chip can hold, between 12 and 64 survivors each.
+  // Measured (survivors per item: ms a frame): 512^2 / 1000 photons 12: 0.0345, 16: 0.0335, 24: 0.0336, 32: 0.0368;
+  // 10 000 photons 32: 0.162, 48: 0.159, 64: 0.163, 96: 0.173; 1024^2 / 100 000 photons 64: 3.13, 128: 2.94, 192: 2.92,
+  // 256: 2.93; the heterogeneous estimator (its items end with a partly filled drain of queued pairs, but a pair costs
+  // it four times as much) 32: 0.728, 48: 0.720, 64: 0.716, 96: 0.733, 128: 0.735.
+  const bool queued = mode != PB_MODE_721;
+  int length = (int)(total / ((queued ? 6 : 3) * 8192));
+  const int longest = queued ? 128 : 192;
+  length = length < 16 ? 16 : (length > longest ? longest : length);
+  if (p.strip_stride > 1) length = length / 2 < 16 ? 16 : length / 2;       // a rank's share of the strips: fewer items
+  // an item's survivors must fit the LDS list of whichever kernel evaluates it
+  const int most = pb_max_item_survivors();
+  if (const char* e = std::getenv("PB_TUNE_SURV")) { int v = std::atoi(e); if (v >= 1) length = v; }
+  if (length > most) length = most;
+  PB_HIP(hipMemsetAsync(regroup_cnt, 0, sizeof(uint32_t) * (size_t)slots, s));
+  rc = pb_launch_regroup_items(p, false, n_old, length, regroup_cnt, nullptr, s);
+  if (rc != PB_OK) return rc;
+  rc = pb_exclusive_scan_u32(regroup_cnt, regroup_off, slots, d_items_total, scan_tmp, s);
+  if (rc != PB_OK) return rc;
+  PB_HIP(hipMemcpyAsync(ctx->h_ctrl, d_items_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  PB_HIP(hipStreamSynchronize(s));
+  const size_t n_new = ctx->h_ctrl[0];
+  if (n_new > (size_t)(1u << 30)) return PB_OK;          // not kept: the frame goes on with the queue as built
+  if (total > ws.ws_surv_cap) {
+    if (ws.d_surv_list) PB_HIP(hipFree(ws.d_surv_list));
+    ws.d_surv_list = nullptr; ws.ws_surv_cap = 0;
+    const size_t cap = total + total / 8 + 1024;
+    PB_HIP(hipMalloc(&ws.d_surv_list, sizeof(uint32_t) * cap));
+    ws.ws_surv_cap = cap;
+  }
+  if (n_new > (size_t)ws.ws_items_kept_cap) {
+    if (ws.d_items_kept) PB_HIP(hipFree(ws.d_items_kept));
+    ws.d_items_kept = nullptr; ws.ws_items_kept_cap = 0;
+    const size_t cap = n_new + n_new / 8 + 1024;
+    PB_HIP(hipMalloc(&ws.d_items_kept, sizeof(uint32_t) * 4 * cap));
+    ws.ws_items_kept_cap = (int)cap;
+  }
+  p.surv_list = ws.d_surv_list;
+  rc = pb_launch_refine_items(p, true, s);
+  if (rc != PB_OK) return rc;
+  rc = pb_launch_regroup_items(p, true, n_old, length, regroup_off, ws.d_items_kept, s);
+  if (rc != PB_OK) return rc;
+  ws.ws_items_kept = (int)n_new;
+  ws.surv_ready = true;
+  return PB_OK;
+}
+
 // Frame through screen-space bins (cull mode 2); p is complete except for the workspace pointers.
 int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, const unsigned long long key_in[6], hipStream_t s) {
   // Lane-per-macro-tile binning tests every segment against every macro tile and keeps a counter per (block of 128
@@ -275,6 +355,9 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
   unsigned long long key[6];
   std::memcpy(key, key_in, sizeof(key));
   key[4] |= ((unsigned long long)(uint32_t)fused_max_seg + 1ull) << 8;
+  // whether the kept queue's items hold survivors (build_survivor_lists) or candidates is part of what is kept
+  const bool keep_survivors = !ws.fixed && !std::getenv("PB_TUNE_NO_PREFINE");
+  key[4] |= (keep_survivors ? 1ull : 0ull) << 48;
   const int tiles = p.tiles_x * p.tiles_y;
   const int groups = tiles * p.ssaa * p.ssaa;
   const size_t px = (size_t)tiles * 64;      // pixel sums are stored per tile
@@ -367,15 +450,40 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       // in the workspace from the frame that sized it for this key (as a tree would be kept): ray set-up, evaluation,
       // pixels.  PB_TUNE_REFILL fills the lists again every frame (the binning pass beside the ray set-up).
       p.n_items_host = ws.ws_items_needed;
+      p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !pb_residue_frame(p, mode) && !std::getenv("PB_SEPARATE_FINALIZE")) ? 1 : 0;
+      bool made_now = false;
+      if (!ws.surv_ready && keep_survivors) {
+        // the first kept frame of this queue: it also tests every item's candidates once and for all and cuts the
+        // queue anew by survivors; its ray set-up runs first (the tests read the tiles' planes from the ray blocks and
+        // group_last), against the per-tile item counts of the queue as built
+        rc = pb_launch_fast_frame(p, mode, !std::getenv("PB_TUNE_REFILL"), s, 1);
+        if (rc != PB_OK) return rc;
+        rc = build_survivor_lists(ctx, ws, p, mode, slots, s);
+        if (rc != PB_OK) return rc;
+        made_now = ws.surv_ready;
+      }
+      if (ws.surv_ready) {
+        p.items = ws.d_items_kept; p.item_capacity = ws.ws_items_kept_cap; p.n_items_host = ws.ws_items_kept;
+        p.surv_list = ws.d_surv_list; p.kept_queue = 1;
+      }
       // runs of 64 queue items per XCD: a tile's items share an L2 (cfg2: 91 -> 60 MB fetched by the evaluation, same
       // time; 512^2 / 1000 photons 0.0447 -> 0.0420 ms); frames with very many items lose 2 % to it and deal singly
-      if (p.xcd_run < 0) p.xcd_run = ws.ws_items_needed <= (1 << 17) ? 64 : 0;
-      p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !pb_residue_frame(p, mode) && !std::getenv("PB_SEPARATE_FINALIZE")) ? 1 : 0;
-      rc = pb_launch_fast_frame(p, mode, !std::getenv("PB_TUNE_REFILL"), s);
+      if (p.xcd_run < 0) p.xcd_run = p.n_items_host <= (1 << 17) ? 64 : 0;
+      if (made_now) {
+        // the set-up above prepared the sums and the black tiles for the old per-tile item counts: once more for the new
+        rc = pb_launch_fast_frame(p, mode, true, s, 1);
+        if (rc != PB_OK) return rc;
+        rc = pb_launch_fast_frame(p, mode, true, s, 2);
+      }
+      else if (keep_survivors && !ws.surv_ready) {       // the lists could not be made: stage 1 has run
+        rc = pb_launch_fast_frame(p, mode, true, s, 2);
+      }
+      else rc = pb_launch_fast_frame(p, mode, !std::getenv("PB_TUNE_REFILL"), s);
       if (rc != PB_OK) return rc;
       if (ctx->count_on || ctx->time_render) { PB_HIP(hipEventRecord(ctx->ev[1], s)); ctx->ev_valid[0] = true; }
       return PB_OK;
     }
+    ws.surv_ready = false;        // the passes below write the item queue anew, every item over its candidates again
     if (!p.fused_queue) {
       PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
       PB_HIP(hipMemsetAsync(ws.d_ctrl, 0, sizeof(uint32_t) * 4, s));
@@ -633,7 +741,8 @@ void pb_destroy(pb_ctx* ctx) {
                   ctx->d_het, ctx->d_het_axis, ctx->d_het_fast, ctx->d_grid, ctx->d_out, ctx->d_counters, ctx->d_beams, ctx->d_beams_spare, ctx->d_emit_tmp[0],
                   ctx->d_emit_tmp[1], ctx->d_emit_tmp[2], ctx->ws.d_rays, ctx->ws.d_group_last,
                   ctx->ws.d_chunks, ctx->ws.d_partials, ctx->ws.d_ctrl, ctx->ws.d_tile_u32, ctx->ws.d_bin_list, ctx->ws.d_blk,
-                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->ws.d_walk, ctx->ws.d_residue, ctx->lb_pool};
+                  ctx->ws.d_items, ctx->ws.d_accum, ctx->ws.d_scan_tmp, ctx->ws.d_walk, ctx->ws.d_residue, ctx->ws.d_surv_list,
+                  ctx->ws.d_surv_cnt, ctx->ws.d_items_kept, ctx->lb_pool};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
   for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);

@@ -159,7 +159,10 @@ struct RenderParams {
   uint32_t* blk;            // [binning blocks][macro tiles] lane-per-macro-tile binning: a block's count per macro tile, turned
                             // into the start of its range inside that macro tile's list by queue_build_kernel
   unsigned long long* bin_mask;   // [n_seg][PB_BIN_FAN] what the counting pass of the rectangle walk found (bit 63: valid), or null
-  uint32_t* items;          // [items][4]: group, start, n, 0
+  uint32_t* items;          // [items][4]: group, start, n, refined: 0 = n candidates at bin_list + start, still to be tested against
+                            // the tile's pyramid; 1 = n survivors of that test at surv_list + start
+  uint32_t* surv_list;      // the items' survivors, item after item in queue order (kept with the item queue)
+  uint32_t* surv_cnt;       // [items] survivors per item, then [items] their offsets (while the lists are made)
   uint32_t* item_off;       // [queue slots] first item of the tile in that slot (macro tiles in rank order)
   uint32_t* macro_cnt;      // [macro tiles] list length
   uint32_t* macro_rank;     // [macro tiles] position in the evaluation queue, longest list first
@@ -174,6 +177,7 @@ struct RenderParams {
   int macro_h;              // tile rows per macro tile (fewer when the rows are interleaved strips)
   int fused_queue;          // 1: ray set-up clears the accumulators and one block builds the queue (small frames)
   int n_items_host;         // number of items of this frame as measured when the workspace was sized
+  int kept_queue;           // items is the kept queue of survivors (n_items_host of them; ctrl[0] still counts the queue as built)
   int slice;                // candidates of a macro list per evaluation item (<= PB_SLICE)
   int slice_whole;          // a list of at most this many candidates is one item whatever `slice` (<= PB_SLICE; 0: none)
   int eval_waves;           // size of the persistent evaluation grid
@@ -230,6 +234,13 @@ struct FrameWorkspace {
   uint32_t* d_scan_tmp = nullptr;
   float* d_walk = nullptr;             // per ray group: the view rays' tabulated grid walks (heterogeneous medium only)
   int ws_walk_groups = 0;
+  uint32_t* d_surv_list = nullptr;     // survivors of every item's candidates (RenderParams::surv_list), kept with the queue
+  size_t ws_surv_cap = 0;
+  uint32_t* d_surv_cnt = nullptr;      // per item: survivor count, offset; per queue slot: new items, their offset; scan scratch
+  size_t ws_surv_words = 0;            // words d_surv_cnt holds
+  uint32_t* d_items_kept = nullptr;    // the kept queue: items of survivors (RenderParams::items of the kept frames)
+  int ws_items_kept_cap = 0, ws_items_kept = 0;
+  bool surv_ready = false;             // d_items_kept / d_surv_list / tile_items describe the frame of ws_key
   uint2* d_residue = nullptr;          // device-wide queue of pairs for the exact-order code (relaxed heterogeneous estimator)
   int ws_residue_cap = 0;
   int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_items_needed = 0;
@@ -373,7 +384,14 @@ PB_HDI int pb_macro_count(const RenderParams& p) {
   return ((p.tiles_x + p.macro_w - 1) / p.macro_w) * ((p.tiles_y + p.macro_h - 1) / p.macro_h);
 }
 int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStream_t s);
-int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, hipStream_t s);
+// stage: 0 = the whole frame, 1 = only what comes before the evaluation, 2 = only the evaluation and what follows it
+int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, hipStream_t s, int stage = 0);
+// One pass over the item queue that tests every item's candidates against its tile's pyramid: write = false counts the
+// survivors (surv_cnt[item]); write = true stores them at surv_list + surv_cnt[n_items + item] and repoints the item.
+int pb_launch_refine_items(const RenderParams& p, bool write, hipStream_t s);
+int pb_max_item_survivors(void);      // the shortest LDS survivor list among the kernels that evaluate items
+// The kept queue cut anew into items of at most `length` survivors (regroup_items_kernel).
+int pb_launch_regroup_items(const RenderParams& p, bool write, int n_old, int length, uint32_t* regroup, uint32_t* items_kept, hipStream_t s);
 bool pb_residue_frame(const RenderParams& p, int mode);   // the frame's evaluation hands pairs to a residue launch (pixels written after it)
 
 #endif

@@ -61,9 +61,15 @@ PB_DI uint32_t lanes_below(unsigned long long mask) {
 // next 64 list entries are requested before the current ones are tested, and a candidate's two cap records are requested
 // together (left to itself the compiler waits for the first before it asks for the second).  At eight waves to a SIMD the
 // plain loop is faster (512^2, 17 424 segments: 0.1937 against 0.1952 ms; 0.1955 with only the caps requested together).
+// refined (wave-uniform, the item's fourth word): the item's list already holds survivors, copied as they are.
 template <bool AHEAD>
-PB_DI int refine_candidates(const RenderParams& p, uint32_t start, int cn, const V3 pl[4], uint32_t* surv, int lane) {
+PB_DI int refine_candidates(const RenderParams& p, uint32_t start, int cn, const V3 pl[4], uint32_t* surv, int lane, uint32_t refined) {
   int ns = 0;
+  if (refined) {
+    const uint32_t* kept = p.surv_list + start;
+    for (int base = 0; base < cn; base += 64) { const int k = base + lane; if (k < cn) surv[k] = kept[k]; }
+    return cn;
+  }
   const uint32_t* list = p.bin_list + start;
   if (!AHEAD) {
     for (int base = 0; base < cn; base += 64) {
@@ -1197,7 +1203,7 @@ template <bool COUNT, bool PRECISE, int MODE>
 PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
   const int lane = threadIdx.x;
   unsigned long long c_cand = 0, c_cyl = 0, c_valid = 0, c_wrong = 0;
-  const uint32_t produced = p.ctrl[0];
+  const uint32_t produced = p.kept_queue ? (uint32_t)p.n_items_host : p.ctrl[0];   // a kept queue has been cut anew since it was built
   const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
   const int nsub = p.ssaa * p.ssaa;
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
@@ -1230,7 +1236,11 @@ PB_DI void eval_bins_body(const RenderParams& p, uint32_t* surv) {
       // 1. lanes test the candidates against this tile's pyramid, REFINE_UNROLL x 64 at a time;
       //    survivors are compacted into LDS
       int ns = 0;
-      for (int base = 0; base < cn; base += 64 * REFINE_UNROLL) {
+      if (it[3]) {                              // a kept queue whose items hold survivors already
+        for (int base = 0; base < cn; base += 64) { const int k = base + lane; if (k < cn) surv[k] = p.surv_list[start + k]; }
+        ns = cn;
+      }
+      else for (int base = 0; base < cn; base += 64 * REFINE_UNROLL) {
         uint32_t cand[REFINE_UNROLL];
         float4 ca[REFINE_UNROLL], cb[REFINE_UNROLL];
 #pragma unroll
@@ -1472,20 +1482,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const int cn = (int)it[2];
   const int tile = group / (p.ssaa * p.ssaa);
   const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
-  V3 pl[4];
-  {
-    const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
-    pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
-  }
+  const uint32_t refined = it[3];
   Ray r;
   r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
   r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
   r.maxd = rr[6 * 64 + lane];
   r.d1 = r.dn;
   r.active = r.maxd >= 0.0f;
-  // 1. lanes test the candidates against this tile's pyramid, 64 at a time; survivors are compacted into LDS
-  int ns = refine_candidates<false>(p, start, cn, pl, surv, lane);
-  __syncthreads();
+  // 1. lanes test the candidates against this tile's pyramid, 64 at a time; survivors are compacted into LDS - unless
+  //    the item is one of a kept queue and holds survivors already: those are read where they lie
+  int ns = cn;
+  const uint32_t* kept = p.surv_list + start;
+  if (!refined) {
+    V3 pl[4];
+    const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
+    pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
+    ns = refine_candidates<false>(p, start, cn, pl, surv, lane, 0u);
+    __syncthreads();
+  }
   // A SIMD shares its issue slots among up to eight items, and the kernel ends with its longest one: items with many
   // survivors go first in the SIMD's arbitration, the short ones fill the slots they leave.
   if (ns > 32) __builtin_amdgcn_s_setprio(3);
@@ -1503,7 +1517,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   if (p.debug & 256) return;             // timing experiment: no pair loop, no write-out
   for (int b0 = 0; b0 < ns; b0 += 64) {
     const int nb = (ns - b0) < 64 ? (ns - b0) : 64;
-    const int mine = (lane < nb) ? (int)surv[b0 + lane] : 0;
+    const int mine = (lane < nb) ? (int)(refined ? kept[b0 + lane] : surv[b0 + lane]) : 0;
     uint32_t off_cur = (uint32_t)__builtin_amdgcn_readlane(mine, 0) * (uint32_t)sizeof(SegFrame);
     u32x16 ra, rb;
     smem_load16(ra, frames, off_cur);
@@ -1520,6 +1534,75 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (k < nb) pair_step(frames, ra, rb, off_cur, off_cur, r, extinction, sum);
   }
   item_writeout<FINALIZE>(p, tile, lane, sum);
+}
+
+// Which of an item's candidates can touch its tile is a function of the segment set and the frame geometry, like the
+// lists and the queue themselves: the frame that sizes the workspace for them also runs the test once for every item
+// (two passes over the queue: count, prefix sum on the host's side of the launch, write) and leaves the survivors
+// behind the queue; every later frame of that segment set and geometry starts its items at the pair loop.  One wave per
+// item; the rays' row of tile planes must be in place (any frame of this geometry and scene has written it).
+template <bool WRITE>
+__global__ __launch_bounds__(64) void refine_items_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[PB_SLICE];
+  const int lane = threadIdx.x;
+  const uint32_t n_items = (uint32_t)p.n_items_host < (uint32_t)p.item_capacity ? (uint32_t)p.n_items_host : (uint32_t)p.item_capacity;
+  const uint32_t c = blockIdx.x;
+  if (c >= n_items) return;
+  const PB_CONST_AS uint32_t* it = pb_uniform(p.items + (size_t)c * 4);
+  const int group = (int)it[0];
+  const uint32_t start = it[1];
+  const int cn = (int)it[2];
+  const uint32_t refined = it[3];
+  const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
+  V3 pl[4];
+  {
+    const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
+    pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
+  }
+  const int ns = refine_candidates<false>(p, start, cn, pl, surv, lane, refined);
+  if (!WRITE) {
+    if (lane == 0) p.surv_cnt[c] = (uint32_t)ns;
+    return;
+  }
+  __syncthreads();
+  const uint32_t at = pb_uniform(p.surv_cnt + n_items)[c];
+  for (int k = lane; k < ns; k += 64) p.surv_list[at + k] = surv[k];
+}
+
+// The kept queue, cut anew by survivors.  A tile's items are neighbours in the queue, so their survivors are one
+// contiguous run of surv_list: [off[first item], off[first item + slices]).  That run is cut into items of at most
+// `length` survivors - every item of the kept queue then carries about the same number of pair-loop steps, where a slice
+// of a macro tile's list left anything from none to all of its candidates.  One lane per tile.  WRITE = false counts
+// the new items per queue slot (regroup_cnt, zeroed before); WRITE = true writes them at regroup_off[slot] into
+// items_kept and the tile's count into tile_items.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void regroup_items_kernel(const RenderParams p, int n_tiles, int n_old, int length,
+                                                            uint32_t* __restrict__ regroup, uint32_t* __restrict__ items_kept) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  const uint32_t* off = p.surv_cnt + n_old;           // n_old + 1 entries: the last one is the total
+  const uint32_t slices = pb_item_slices(p, p.tile_count[t]);
+  const int nsub = p.ssaa * p.ssaa;
+  int m;
+  const int slot = tile_slot(p, t, m);
+  uint32_t c0 = p.item_off[slot];                      // the tile's first item in the queue as it was built
+  uint32_t n_new = 0;
+  const uint32_t at = WRITE ? regroup[slot] : 0u;
+  for (int q = 0; q < nsub; ++q) {
+    if (p.group_last[t * nsub + q] < 0) continue;
+    if (c0 + slices > (uint32_t)n_old) break;          // a queue cut short by its capacity: never kept
+    const uint32_t first = off[c0], total = off[c0 + slices] - first;
+    for (uint32_t done = 0; done < total; done += (uint32_t)length, ++n_new) {
+      if (WRITE) {
+        uint32_t* dst = items_kept + (size_t)(at + n_new) * 4;
+        dst[0] = (uint32_t)(t * nsub + q); dst[1] = first + done;
+        dst[2] = (total - done < (uint32_t)length) ? total - done : (uint32_t)length; dst[3] = 1u;
+      }
+    }
+    c0 += slices;
+  }
+  if (WRITE) p.tile_items[t] = n_new;
+  else regroup[slot] = n_new;
 }
 
 // Integral_73 / Integral_73Het with relaxed arithmetic, in the same one-wave-per-item shape.  What the exact-order
@@ -1684,7 +1767,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
   r.maxd = rr[6 * 64 + lane];
   r.d1 = v3(rr[8 * 64 + lane], rr[9 * 64 + lane], rr[10 * 64 + lane]);
   r.active = r.maxd >= 0.0f;
-  int ns = refine_candidates<true>(p, start, cn, pl, surv, lane);
+  int ns = refine_candidates<true>(p, start, cn, pl, surv, lane, it[3]);
   HetItem h;
   h.frames = p.frames; h.het = p.het_fast;
   h.grid.z = p.grid_z; h.grid.side = p.grid_side; h.grid.fast_div = p.grid_fast_div;
@@ -1834,7 +1917,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   r.maxd = rr[6 * 64 + lane];
   r.d1 = r.dn;
   r.active = r.maxd >= 0.0f;
-  int ns = refine_candidates<true>(p, start, cn, pl, surv, lane);
+  int ns = refine_candidates<true>(p, start, cn, pl, surv, lane, it[3]);
   s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull; s_acc[3][lane] = 0ull;
   __syncthreads();
   GridView grid;
@@ -2056,7 +2139,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   __shared__ float s_ray[GENERIC ? 6 : 3][64];     // the rays' normalised directions (and l, for the 721 integrals)
   __shared__ unsigned long long s_acc[3][64];
   const int lane = threadIdx.x;
-  const uint32_t produced = p.ctrl[0];
+  const uint32_t produced = p.kept_queue ? (uint32_t)p.n_items_host : p.ctrl[0];   // a kept queue has been cut anew since it was built
   const uint32_t n_items = produced < (uint32_t)p.item_capacity ? produced : (uint32_t)p.item_capacity;
   const int nsub = p.ssaa * p.ssaa;
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
@@ -2080,7 +2163,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     s_ray[0][lane] = rr[8 * 64 + lane]; s_ray[1][lane] = rr[9 * 64 + lane]; s_ray[2][lane] = rr[10 * 64 + lane];
     if (GENERIC) { s_ray[3][lane] = r.l.x; s_ray[4][lane] = r.l.y; s_ray[5][lane] = r.l.z; }
     s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull;
-    const int ns = refine_candidates<true>(p, start, cn, pl, surv, lane);
+    const int ns = refine_candidates<true>(p, start, cn, pl, surv, lane, it[3]);
     __syncthreads();
     int pending = 0;
     // the top `take` entries of the queue, one per lane
@@ -2467,9 +2550,32 @@ int pb_launch_bin_fill_eval(const RenderParams& p, int mode, bool count, hipStre
 
 // A frame whose list offsets (sub_off), item queue (items, ctrl[0]) and per-tile list lengths are in the workspace
 // from the frame that sized it for the same segment set and frame geometry: three launches.
-int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, hipStream_t s) {
+int pb_max_item_survivors(void) {
+  static_assert(HET2_SLICE <= PB_SLICE, "eval_items_het2_kernel has the shortest survivor list");
+  return HET2_SLICE;
+}
+
+int pb_launch_refine_items(const RenderParams& p, bool write, hipStream_t s) {
+  if (p.n_items_host <= 0) return PB_OK;
+  if (write) hipLaunchKernelGGL(refine_items_kernel<true>, dim3(p.n_items_host), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(refine_items_kernel<false>, dim3(p.n_items_host), dim3(64), 0, s, p);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}
+
+int pb_launch_regroup_items(const RenderParams& p, bool write, int n_old, int length, uint32_t* regroup, uint32_t* items_kept, hipStream_t s) {
+  const int tiles = p.tiles_x * p.tiles_y;
+  if (tiles <= 0) return PB_OK;
+  if (write) hipLaunchKernelGGL(regroup_items_kernel<true>, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles, n_old, length, regroup, items_kept);
+  else hipLaunchKernelGGL(regroup_items_kernel<false>, dim3((tiles + 255) / 256), dim3(256), 0, s, p, tiles, n_old, length, regroup, items_kept);
+  PB_HIP(hipGetLastError());
+  return PB_OK;
+}
+
+int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, hipStream_t s, int stage) {
   const int groups = p.tiles_x * p.tiles_y * p.ssaa * p.ssaa;
   if (groups <= 0) return PB_OK;
+  if (stage == 2) return launch_eval_finalize(p, mode, false, s);
   const int n_macro = pb_macro_count(p);
   // the lists themselves are a function of the segment set and the frame geometry too: where an earlier frame of both
   // left them in the workspace, no block bins
@@ -2485,10 +2591,12 @@ int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, h
     if (waves == 4) hipLaunchKernelGGL(setup_rays_kernel<256>, dim3((groups + 3) / 4), dim3(256), lds, s, p, groups, scene_in_lds);
     else if (waves == 16) hipLaunchKernelGGL(setup_rays_kernel<1024>, dim3((groups + 15) / 16), dim3(1024), lds, s, p, groups, scene_in_lds);
     else hipLaunchKernelGGL(setup_rays_kernel<512>, dim3((groups + 7) / 8), dim3(512), lds, s, p, groups, scene_in_lds);
+    if (stage == 1) { PB_HIP(hipGetLastError()); return PB_OK; }
     return launch_eval_finalize(p, mode, false, s);
   }
   hipLaunchKernelGGL(setup_fill_kernel, dim3(bin_blocks + ray_blocks), dim3(MBIN_THREADS), lds, s,
                      p, n_macro, bin_blocks, groups, scene_in_lds);
+  if (stage == 1) { PB_HIP(hipGetLastError()); return PB_OK; }
   return launch_eval_finalize(p, mode, false, s);
 }
 

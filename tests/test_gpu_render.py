@@ -498,3 +498,55 @@ def test_both_binning_passes_give_the_same_frame(pb, het, monkeypatch):
     assert ref.max() > 0.05 and np.isfinite(ref).all()
     for f in frames[""][1:] + frames["0"]:
         assert np.array_equal(f, ref)
+
+
+@pytest.mark.parametrize("ssaa", [1, 2])
+def test_kept_queue_of_survivors_gives_the_same_frames(pb, ssaa, monkeypatch):
+    """The frame after the one that sizes the workspace tests every item's candidates against its tile once, keeps the
+    survivors and cuts the queue anew by survivors; later frames start at the pair loop.  Whatever the item length,
+    with or without that step, for either arithmetic and for ragged rectangles the frame is the same, bit for bit
+    (fixed-point sums do not depend on how a tile's pairs are dealt to items)."""
+    import torch
+    W, H = 200, 136
+    kw = dict(screen_width=W, screen_height=H, ssaa=ssaa, photon_number=4000, bounces=2)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def frames(ctx, n, rect=(0, 0, W, H)):
+        x0, y0, w, h = rect
+        out = torch.full((n, h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+        for i in range(n):
+            ctx.draw_device(out[i].data_ptr(), x0, y0, w, h, cull="bins", stream=stream)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    monkeypatch.setenv("PB_TUNE_NO_PREFINE", "1")
+    with pb.Context(pb.control_defaults(**kw)) as ctx:
+        ctx.set_scene(); ctx.cast_photon_beams()
+        plain = frames(ctx, 2)
+        ctx.set_precise(True)
+        plain_precise = frames(ctx, 2)
+        part_plain = frames(ctx, 2, (24, 16, 99, 77))
+    monkeypatch.delenv("PB_TUNE_NO_PREFINE")
+    assert plain.max() > 0 and np.array_equal(plain[0], plain[1])
+    for length in (None, "5", "64", "256"):
+        if length is None:
+            monkeypatch.delenv("PB_TUNE_SURV", raising=False)
+        else:
+            monkeypatch.setenv("PB_TUNE_SURV", length)
+        with pb.Context(pb.control_defaults(**kw)) as ctx:
+            ctx.set_scene(); ctx.cast_photon_beams()
+            got = frames(ctx, 4)          # sizing frame, the frame that makes the lists, two that use them
+            for i in range(4):
+                assert np.array_equal(got[i], plain[0]), (length, i)
+            ctx.set_precise(True)         # the exact-order kernels walk the same kept queue
+            for f in frames(ctx, 2):
+                assert np.array_equal(f, plain_precise[0]), length
+            for f in frames(ctx, 3, (24, 16, 99, 77)):
+                assert np.array_equal(f, part_plain[0]), length
+            ctx.set_precise(False)
+            ctx.enable_counters(True)     # a counted frame builds its queue anew; the next frames keep one again
+            counted = frames(ctx, 1)
+            ctx.enable_counters(False)
+            np.testing.assert_allclose(counted[0], plain[0], rtol=1e-5, atol=1e-7)
+            for f in frames(ctx, 3):
+                assert np.array_equal(f, plain[0]), length

@@ -8,6 +8,7 @@ Passes (each one rocprofv3 run of its own; counters never share a run with --ker
   fp32    SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32, SQ_INSTS_VALU, _SALU, _SMEM, _LDS
   wait    SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY,
           SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_SCA, SQ_WAVES
+  lanes   SQ_THREAD_CYCLES_VALU, SQ_ACTIVE_INST_VALU, SQ_INST_CYCLES_VALU (lane_active_frac = thread-cycles / (64 x cycles))
   fetch   FETCH_SIZE          write   WRITE_SIZE
 The counter passes end in <out_dir>/<W>_pmc.json: per kernel of the timed frames the mean per launch of
 every counter (only kernels launched once per timed step count as the frame's), the hardware-counted FP32 operations per frame (64 lanes x (ADD + MUL + 2 FMA + TRANS)
@@ -30,6 +31,8 @@ PASSES = {
              "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS"],
     "wait": ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
              "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVES"],
+    # share of a vector instruction's 64 lanes that the execution mask leaves on: thread-cycles over 64 x wave-cycles
+    "lanes": ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INST_CYCLES_VALU", "SQ_INSTS_VALU"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
 }
@@ -92,7 +95,7 @@ def counters(d):
 
 def main():
     workload, out_dir = sys.argv[1], os.path.abspath(sys.argv[2])
-    passes = sys.argv[3:] or ["trace", "fp32", "wait", "fetch", "write"]
+    passes = sys.argv[3:] or ["trace", "fp32", "lanes", "wait", "fetch", "write"]
     os.makedirs(out_dir, exist_ok=True)
     per_kernel = defaultdict(dict)
     for name in passes:
@@ -112,8 +115,21 @@ def main():
     # a kernel of the timed frames is launched once per step (20 + 3 warm-up); what the sizing frame and the counted
     # frame launch once or twice is left out
     frame = {k: v for k, v in per_kernel.items() if is_frame_kernel(k) and v.get("launches", 0) >= 20}
-    flops = sum(64.0 * (v.get("SQ_INSTS_VALU_ADD_F32", 0) + v.get("SQ_INSTS_VALU_MUL_F32", 0) +
-                        2 * v.get("SQ_INSTS_VALU_FMA_F32", 0) + v.get("SQ_INSTS_VALU_TRANS_F32", 0)) for v in frame.values())
+    def issued(v):
+        return 64.0 * (v.get("SQ_INSTS_VALU_ADD_F32", 0) + v.get("SQ_INSTS_VALU_MUL_F32", 0) +
+                       2 * v.get("SQ_INSTS_VALU_FMA_F32", 0) + v.get("SQ_INSTS_VALU_TRANS_F32", 0))
+
+    def lane_frac(v):
+        # rocprofv3's own VALUUtilization: SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)
+        cyc = v.get("SQ_ACTIVE_INST_VALU", 0)
+        return min(1.0, v.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * cyc)) if cyc > 0 else None
+    for v in frame.values():
+        v["lane_active_frac"] = lane_frac(v)
+    flops = sum(issued(v) for v in frame.values())
+    # FP32 operations on lanes the execution mask leaves on: each kernel's issued count times its own lane share (the
+    # share is measured over all its vector instructions; the FP32 ones are taken to have the kernel's mean)
+    have_lanes = all(v.get("lane_active_frac") is not None for v in frame.values()) and bool(frame)
+    active = sum(issued(v) * v["lane_active_frac"] for v in frame.values()) if have_lanes else None
     fetch = sum(2 * 1024.0 * v.get("FETCH_SIZE", 0) for v in frame.values())
     write = sum(1024.0 * v.get("WRITE_SIZE", 0) for v in frame.values())
     out = {"workload": workload, "cull": "bins", "source_stamp": source_stamp(),
@@ -122,6 +138,8 @@ def main():
                      "passes and the counted frame; fp32_flop = 64 x (ADD_F32 + MUL_F32 + 2 FMA_F32 + TRANS_F32) wave-level "
                      "instructions; FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)",
            "fp32_flop_per_frame": flops if "fp32" in passes else None,
+           "fp32_flop_active_lanes_per_frame": active if ("fp32" in passes and "lanes" in passes) else None,
+           "lane_active_frac": (active / flops) if (active is not None and flops > 0 and "fp32" in passes) else None,
            "fetch_bytes": fetch if "fetch" in passes else None, "write_bytes": write if "write" in passes else None,
            "traffic_bytes": fetch + write if ("fetch" in passes and "write" in passes) else None,
            "frame_kernels": frame, "other_kernels": {k: v for k, v in per_kernel.items() if k not in frame}}
