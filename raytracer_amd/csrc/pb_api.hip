@@ -304,7 +304,9 @@ int build_survivor_lists(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int m
   const bool queued = mode != PB_MODE_721;
   int length = (int)(total / ((queued ? 6 : 3) * 8192));
   const int longest = queued ? 128 : 192;
-  length = length < 16 ? 16 : (length > longest ? longest : length);
+  // (a frame short enough to be one launch, its items setting up their own rays: 16: 0.0307, 24: 0.0289, 32: 0.0317)
+  const int shortest = queued ? 16 : 24;
+  length = length < shortest ? shortest : (length > longest ? longest : length);
   if (p.strip_stride > 1) length = length / 2 < 16 ? 16 : length / 2;       // a rank's share of the strips: fewer items
   // an item's survivors must fit the LDS list of whichever kernel evaluates it
   const int most = pb_max_item_survivors();
@@ -469,7 +471,19 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       // runs of 64 queue items per XCD: a tile's items share an L2 (cfg2: 91 -> 60 MB fetched by the evaluation, same
       // time; 512^2 / 1000 photons 0.0447 -> 0.0420 ms); frames with very many items lose 2 % to it and deal singly
       if (p.xcd_run < 0) p.xcd_run = p.n_items_host <= (1 << 17) ? 64 : 0;
-      if (made_now) {
+      // A frame of few items per tile is one launch: every item sets up its own rays (eval_items_fast_kernel's INLINE
+      // form), which costs a tile's ray set-up once per item but saves the launch before the evaluation and the rays'
+      // trip through memory.  The sums must have been left clear by the frame before (its last arrivers do that).
+      double inline_ratio = 4.0;
+      if (const char* e = std::getenv("PB_TUNE_INLINE")) inline_ratio = std::atof(e);
+      const bool one_launch = ws.surv_ready && !made_now && ws.sums_left_clear && mode == PB_MODE_721 && p.finalize_in_eval &&
+                              pb_pipelined_eval(p, mode) && !ctx->ctl.short_view &&
+                              (double)p.n_items_host <= inline_ratio * (double)groups;
+      if (one_launch) {
+        p.inline_item_blocks = 1;
+        rc = pb_launch_fast_frame(p, mode, true, s, 2);
+      }
+      else if (made_now) {
         // the set-up above prepared the sums and the black tiles for the old per-tile item counts: once more for the new
         rc = pb_launch_fast_frame(p, mode, true, s, 1);
         if (rc != PB_OK) return rc;
@@ -480,10 +494,12 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       }
       else rc = pb_launch_fast_frame(p, mode, !std::getenv("PB_TUNE_REFILL"), s);
       if (rc != PB_OK) return rc;
+      ws.sums_left_clear = mode == PB_MODE_721 && p.finalize_in_eval && pb_pipelined_eval(p, mode);
       if (ctx->count_on || ctx->time_render) { PB_HIP(hipEventRecord(ctx->ev[1], s)); ctx->ev_valid[0] = true; }
       return PB_OK;
     }
     ws.surv_ready = false;        // the passes below write the item queue anew, every item over its candidates again
+    ws.sums_left_clear = false;
     if (!p.fused_queue) {
       PB_HIP(hipMemsetAsync(p.item_off, 0, sizeof(uint32_t) * (size_t)slots, s));   // slots of tiles outside the frame stay empty
       PB_HIP(hipMemsetAsync(ws.d_ctrl, 0, sizeof(uint32_t) * 4, s));

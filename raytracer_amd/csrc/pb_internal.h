@@ -177,6 +177,8 @@ struct RenderParams {
   int macro_h;              // tile rows per macro tile (fewer when the rows are interleaved strips)
   int fused_queue;          // 1: ray set-up clears the accumulators and one block builds the queue (small frames)
   int n_items_host;         // number of items of this frame as measured when the workspace was sized
+  int inline_item_blocks;   // > 0: the frame is one launch whose items set up their own rays (host: a request; kernel: the number
+                            // of blocks that evaluate items, the blocks behind them blacken the tiles without items)
   int kept_queue;           // items is the kept queue of survivors (n_items_host of them; ctrl[0] still counts the queue as built)
   int slice;                // candidates of a macro list per evaluation item (<= PB_SLICE)
   int slice_whole;          // a list of at most this many candidates is one item whatever `slice` (<= PB_SLICE; 0: none)
@@ -241,6 +243,7 @@ struct FrameWorkspace {
   uint32_t* d_items_kept = nullptr;    // the kept queue: items of survivors (RenderParams::items of the kept frames)
   int ws_items_kept_cap = 0, ws_items_kept = 0;
   bool surv_ready = false;             // d_items_kept / d_surv_list / tile_items describe the frame of ws_key
+  bool sums_left_clear = false;        // the last frame ended with every multi-item tile's sums and arrival counter at zero
   uint2* d_residue = nullptr;          // device-wide queue of pairs for the exact-order code (relaxed heterogeneous estimator)
   int ws_residue_cap = 0;
   int ws_tiles = 0, ws_bin_cap = 0, ws_item_cap = 0, ws_items_needed = 0;

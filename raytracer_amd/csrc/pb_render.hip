@@ -545,9 +545,11 @@ __global__ __launch_bounds__(64) void reduce_kernel(const RenderParams p) {
 // point (PB_FIX_MAGIC), which makes the sum independent of that order and the image reproducible bit
 // for bit.
 // ---------------------------------------------------------------------------
-// tris / tri_box: the prepared scene in global memory, or the copy the launch staged in LDS.
-template <bool COUNT, class TriPtr, class BoxPtr, class EdgePtr>
-PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tris, BoxPtr tri_box, EdgePtr tri_edge) {
+// The camera rays of a ray group (an 8x8 tile, one sub-sample), one per lane: DrawStandard's per-pixel set-up
+// (skeleton.cpp:342-350) and the root gate.  A ray that is outside the image, misses the scene or fails the root gate
+// comes back with maxd = -1.
+template <class TriPtr, class BoxPtr, class EdgePtr>
+PB_DI Ray group_rays(const RenderParams& p, int group, int lane, TriPtr tris, BoxPtr tri_box, EdgePtr tri_edge, bool& hit_scene) {
   const int nsub = p.ssaa * p.ssaa;
   const int tile = group / nsub, sub = group % nsub;
   const int si = sub / p.ssaa, sj = sub % p.ssaa;
@@ -555,31 +557,6 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
   const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
   const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + (lane >> 3);
   const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
-  if (p.residue && group == 0) {      // the frame's residue queues start empty
-    uint32_t* counters = (uint32_t*)p.residue;
-    for (int q = lane; q < PB_RESIDUE_QUEUES; q += 64) counters[q * 32] = 0u;
-  }
-  if (p.fused_queue) {
-    // this launch also clears the pixel sums the frame accumulates into (the bin counters are cleared by
-    // the previous frame's finalize_kernel)
-    if (sub == 0) {
-      unsigned long long* a = p.accum + (size_t)tile * PB_ACC_PLANES * 64 + lane;   // [tile][plane][lane]
-      if (p.finalize_in_eval) {
-        // no evaluation item will come by this tile: its pixels are written here; a single item writes them itself
-        // and needs no sums
-        const uint32_t items_of_tile = pb_uniform(p.tile_items)[tile];
-        if (items_of_tile > 1u) {
-          a[0] = 0ull; a[64] = 0ull; a[128] = 0ull; a[192] = 0ull;
-          if (lane == 0) p.tile_done[tile] = 0u;
-        } else if (items_of_tile == 0u && ox < p.out_w && oy < p.out_h) {
-          float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
-          o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
-        }
-      } else {
-        a[0] = 0ull; a[64] = 0ull; a[128] = 0ull; a[192] = 0ull;
-      }
-    }
-  }
   // Triangles whose screen box misses the whole tile are ruled out once per wave (lane i looks at triangle i)
   // instead of once per ray; the per-ray box test and the exact intersection see the rest unchanged.
   unsigned long long tri_mask = ~0ull;
@@ -609,9 +586,48 @@ PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tri
   }
   Ray r = make_ray(p, px * p.ssaa + si, py * p.ssaa + sj, tri_mask, tris, tri_box);
   r.active = r.active && in_image;
-  const bool hit_scene = r.active;
+  hit_scene = r.active;
   r.active = r.active && box_gate(p.root.lo, p.root.hi, p.root.cand, p.root.qflags, r.dn, r.maxd);
   if (!r.active) r.maxd = -1.0f;
+  return r;
+}
+
+// tris / tri_box: the prepared scene in global memory, or the copy the launch staged in LDS.
+template <bool COUNT, class TriPtr, class BoxPtr, class EdgePtr>
+PB_DI void ray_setup_body(const RenderParams& p, int group, int lane, TriPtr tris, BoxPtr tri_box, EdgePtr tri_edge) {
+  const int nsub = p.ssaa * p.ssaa;
+  const int tile = group / nsub, sub = group % nsub;
+  const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
+  const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
+  const int px = p.x0 + ox, py = p.y0 + 8 * tk * p.strip_stride + (lane >> 3);
+  const bool in_image = (ox < p.out_w) && (oy < p.out_h) && (px < p.width) && (py < p.height);
+  if (p.residue && group == 0) {      // the frame's residue queues start empty
+    uint32_t* counters = (uint32_t*)p.residue;
+    for (int q = lane; q < PB_RESIDUE_QUEUES; q += 64) counters[q * 32] = 0u;
+  }
+  if (p.fused_queue) {
+    // this launch also clears the pixel sums the frame accumulates into (the bin counters are cleared by
+    // the previous frame's finalize_kernel)
+    if (sub == 0) {
+      unsigned long long* a = p.accum + (size_t)tile * PB_ACC_PLANES * 64 + lane;   // [tile][plane][lane]
+      if (p.finalize_in_eval) {
+        // no evaluation item will come by this tile: its pixels are written here; a single item writes them itself
+        // and needs no sums
+        const uint32_t items_of_tile = pb_uniform(p.tile_items)[tile];
+        if (items_of_tile > 1u) {
+          a[0] = 0ull; a[64] = 0ull; a[128] = 0ull; a[192] = 0ull;
+          if (lane == 0) p.tile_done[tile] = 0u;
+        } else if (items_of_tile == 0u && ox < p.out_w && oy < p.out_h) {
+          float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
+          o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+        }
+      } else {
+        a[0] = 0ull; a[64] = 0ull; a[128] = 0ull; a[192] = 0ull;
+      }
+    }
+  }
+  bool hit_scene;
+  Ray r = group_rays(p, group, lane, tris, tri_box, tri_edge, hit_scene);
   float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
   rr[0 * 64 + lane] = r.l.x; rr[1 * 64 + lane] = r.l.y; rr[2 * 64 + lane] = r.l.z;
   rr[3 * 64 + lane] = r.dn.x; rr[4 * 64 + lane] = r.dn.y; rr[5 * 64 + lane] = r.dn.z;
@@ -1444,8 +1460,11 @@ PB_DI void item_writeout(const RenderParams& p, int tile, int lane, const PairSu
     before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
     if (before + 1u == items_of_tile) {
       asm volatile("" : : : "memory");
-      const unsigned long long vg = atomicAdd(&dst[192], 0ull);
-      const unsigned long long v0 = atomicAdd(&dst[0], 0ull) + vg, v1 = atomicAdd(&dst[64], 0ull) + vg, v2 = atomicAdd(&dst[128], 0ull) + vg;
+      // fetched by exchange with zero: the sums and the arrival counter are left as the next frame needs them, so a
+      // frame whose items set up their own rays (no launch before the evaluation that could clear them) can follow
+      const unsigned long long vg = atomicExch(&dst[192], 0ull);
+      const unsigned long long v0 = atomicExch(&dst[0], 0ull) + vg, v1 = atomicExch(&dst[64], 0ull) + vg, v2 = atomicExch(&dst[128], 0ull) + vg;
+      if (lane == 0) __hip_atomic_store(&p.tile_done[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int tx = tile % p.tiles_x, tk = tile / p.tiles_x;
       const int ox = 8 * tx + (lane & 7), oy = 8 * tk + (lane >> 3);
       if (ox < p.out_w && oy < p.out_h) {
@@ -1459,10 +1478,31 @@ PB_DI void item_writeout(const RenderParams& p, int tile, int lane, const PairSu
   }
 }
 
-template <bool FINALIZE>
+// INLINE (kept queues of survivors only): the frame is this one launch.  Every item sets up its tile's rays itself
+// (group_rays, the scene read through the scalar and vector caches) instead of reading them from a ray block an earlier
+// launch wrote; the blocks behind the items write the black pixels of the tiles that have no item (one lane per tile
+// looks, the wave writes).  The sums of tiles with several items and their arrival counters are zero when the frame
+// starts because the last arriver of the frame before left them so.
+template <bool FINALIZE, bool INLINE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_items_fast_kernel(const RenderParams p) {
-  __shared__ uint32_t surv[PB_SLICE];
+  __shared__ uint32_t surv[INLINE ? 1 : PB_SLICE];
   const int lane = threadIdx.x;
+  if (INLINE && (int)blockIdx.x >= p.inline_item_blocks) {
+    const int n_tiles = p.tiles_x * p.tiles_y;
+    const int t = ((int)blockIdx.x - p.inline_item_blocks) * 64 + lane;
+    unsigned long long empty = __ballot(t < n_tiles && p.tile_items[t < n_tiles ? t : 0] == 0u);
+    while (empty) {
+      const int j = __builtin_ctzll(empty);
+      empty &= empty - 1ull;
+      const int tile = ((int)blockIdx.x - p.inline_item_blocks) * 64 + j;
+      const int ox = 8 * (tile % p.tiles_x) + (lane & 7), oy = 8 * (tile / p.tiles_x) + (lane >> 3);
+      if (ox < p.out_w && oy < p.out_h) {
+        float* o = p.out + ((size_t)oy * p.out_w + ox) * 3;
+        o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+      }
+    }
+    return;
+  }
   // the number of items is the one the host measured when it sized the workspace for this segment set and frame
   // (the queue build leaves the same number in ctrl[0]): an argument instead of a trip to memory before the first load
   const uint32_t produced = (uint32_t)p.n_items_host;
@@ -1482,13 +1522,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const int cn = (int)it[2];
   const int tile = group / (p.ssaa * p.ssaa);
   const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
-  const uint32_t refined = it[3];
+  const uint32_t refined = INLINE ? 1u : it[3];
   Ray r;
-  r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
-  r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
-  r.maxd = rr[6 * 64 + lane];
-  r.d1 = r.dn;
-  r.active = r.maxd >= 0.0f;
+  if (INLINE) {
+    bool hit_scene;
+    r = group_rays(p, group, lane, p.tris, p.tri_box, p.tri_edge, hit_scene);
+  } else {
+    r.l = v3(rr[0 * 64 + lane], rr[1 * 64 + lane], rr[2 * 64 + lane]);
+    r.dn = v3(rr[3 * 64 + lane], rr[4 * 64 + lane], rr[5 * 64 + lane]);
+    r.maxd = rr[6 * 64 + lane];
+    r.d1 = r.dn;
+    r.active = r.maxd >= 0.0f;
+  }
   // 1. lanes test the candidates against this tile's pyramid, 64 at a time; survivors are compacted into LDS - unless
   //    the item is one of a kept queue and holds survivors already: those are read where they lie
   int ns = cn;
@@ -2518,6 +2563,15 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
   else if (p.precise) hipLaunchKernelGGL((eval_bins_kernel<false, true, PB_MODE_721>), dim3(waves), dim3(64), 0, s, p);
   else if (pb_pipelined_eval(p, mode)) {
     if (p.xcd_run > 0) waves = (waves + 8 * p.xcd_run - 1) / (8 * p.xcd_run) * (8 * p.xcd_run);    // whole runs for every XCD
+    if (p.inline_item_blocks > 0) {
+      // the whole frame: items that set up their own rays, then the blocks that blacken the tiles without items
+      RenderParams q = p;
+      q.inline_item_blocks = waves;
+      const int tiles = p.tiles_x * p.tiles_y;
+      hipLaunchKernelGGL((eval_items_fast_kernel<true, true>), dim3(waves + (tiles + 63) / 64), dim3(64), 0, s, q);
+      PB_HIP(hipGetLastError());
+      return PB_OK;
+    }
     if (p.finalize_in_eval) {
       hipLaunchKernelGGL(eval_items_fast_kernel<true>, dim3(waves), dim3(64), 0, s, p);
       PB_HIP(hipGetLastError());

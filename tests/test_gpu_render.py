@@ -528,8 +528,14 @@ def test_kept_queue_of_survivors_gives_the_same_frames(pb, ssaa, monkeypatch):
         part_plain = frames(ctx, 2, (24, 16, 99, 77))
     monkeypatch.delenv("PB_TUNE_NO_PREFINE")
     assert plain.max() > 0 and np.array_equal(plain[0], plain[1])
-    for length in (None, "5", "64", "256"):
-        if length is None:
+    for length in (None, "5", "64", "256", "one launch", "two launches"):
+        # frames of few items per tile are one launch whose items set up their own rays; forced on and off here
+        monkeypatch.delenv("PB_TUNE_INLINE", raising=False)
+        if length == "one launch":
+            monkeypatch.setenv("PB_TUNE_INLINE", "1000"); monkeypatch.setenv("PB_TUNE_SURV", "24")
+        elif length == "two launches":
+            monkeypatch.setenv("PB_TUNE_INLINE", "0"); monkeypatch.setenv("PB_TUNE_SURV", "24")
+        elif length is None:
             monkeypatch.delenv("PB_TUNE_SURV", raising=False)
         else:
             monkeypatch.setenv("PB_TUNE_SURV", length)
