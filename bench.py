@@ -15,6 +15,7 @@ Workloads (BASELINE.json `configs`):
   cfg2  512^2, 10000 photons, BOUNCES 3
   cfg3  512^2, 10000 photons, BOUNCES 3, heterogeneous medium (Integral_73Het estimator)
   cfg4  1024^2, 100000 photons, BOUNCES 0
+  cfg5  4096^2, 1000000 photons, BOUNCES 3, heterogeneous medium, in bands of 512 rows (under `other_workloads` on one GPU)
 The line's `value`, `roofline` and `cpu_baseline` belong to --workload; `other_workloads` holds the same
 measurement, shorter, for the rest (skipped with --only).
 """
@@ -37,7 +38,11 @@ WORKLOADS = {
     "cfg3": dict(screen_width=512, screen_height=512, photon_number=10000, bounces=3, heterogeneous=1, one_dimensional=1),
     "cfg4": dict(screen_width=1024, screen_height=1024, photon_number=100000, bounces=0),
 }
-OTHER_STEPS = {"cfg1": 50, "cfg2": 50, "cfg3": 10, "cfg4": 10}
+# BASELINE's fifth configuration (LBVH build / traversal stress): one GPU renders it as bands of rows, so that no launch
+# runs for seconds; its line has no `roofline` (a counted frame would test 16.8 M rays against 23.7 M gate boxes)
+BANDED = {"cfg5": dict(screen_width=4096, screen_height=4096, photon_number=1000000, bounces=3, heterogeneous=1,
+                       one_dimensional=1, band_rows=512)}
+OTHER_STEPS = {"cfg1": 50, "cfg2": 50, "cfg3": 10, "cfg4": 10, "cfg5": 2}
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 peak: 256 CUs x 4 SIMDs x 32 lanes x 2 (FMA) x 2.4 GHz
 STALL_SECONDS = 120        # a multi-rank run that stands still this long prints where and ends
 
@@ -188,6 +193,63 @@ class Bench:
             self.dist.barrier()
             self.dist.destroy_process_group()
             faulthandler.cancel_dump_traceback_later()
+
+    def run_banded(self, name, steps, warmup):
+        """A frame too long for one launch, on one GPU: photon pass + LBVH (once), then `warmup` + `steps` frames, each a
+        sequence of row bands through pb_render_d's pixel rectangle into one resident image."""
+        torch, pb, dev = self.torch, self.pb, self.dev
+        wk = dict(BANDED[name])
+        band = wk.pop("band_rows")
+        ctl = pb.control_defaults(**wk)
+        W, H = wk["screen_width"], wk["screen_height"]
+        ctx = pb.Context(ctl, device=self.local_rank)
+        ctx.set_scene()
+        grid = pb.make_grid()
+        ctx.set_grid(*grid)
+        ctx.cast_photon_beams()
+        ctx.build_tree()
+        n_beams, n_segs = ctx.cast_photon_beams()      # warm: the buffers of the first pass are in place
+        t_build = time.perf_counter()
+        ctx.build_tree()
+        torch.cuda.synchronize()
+        build_wall_ms = (time.perf_counter() - t_build) * 1e3
+        st = ctx.counters()
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def one_frame():
+            for y0 in range(0, H, band):
+                h = min(band, H - y0)
+                ctx.draw_device(frame[y0:y0 + h].data_ptr(), 0, y0, W, h, mode=pb.MODE_73HET, cull="bins", stream=stream)
+        for _ in range(warmup):
+            one_frame()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            one_frame()
+        ev1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rays = W * H
+        frame_ok = bool(torch.isfinite(frame).all().item()) and float(frame.max().item()) > 0
+        out = {"value": rays * steps / dt / 1e6, "unit": "Mray/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+               "config": {"workload": f"{name}: Cornell box {W}x{H}, {wk['photon_number']} photons, BOUNCES {wk['bounces']}, heterogeneous "
+                                      f"medium, SEED 42 (GPU photon pass: {n_beams} beams, {n_segs} segments, own-box gate rule), "
+                                      f"bands of {band} rows, every band binned anew in every frame",
+                          "rays_per_frame": rays, "segments": n_segs, "cull": "bins", "parallelism": "single GPU"},
+               "kernel_ms": ev0.elapsed_time(ev1) / steps, "frame_ok": frame_ok,
+               "lit_fraction": float((frame > 0).any(dim=2).float().mean().item()),
+               "phases_ms": {"ms_emit": st["ms_emit"], "ms_prepare": st["ms_prepare"], "ms_build": st["ms_build"],
+                             "build_wall_ms": build_wall_ms},
+               "phases_gb_per_s": {
+                   "lbvh_build": (6 * 2 * 12 + 128) * n_segs / (st["ms_build"] * 1e-3) / 1e9 if st["ms_build"] > 0 else None,
+                   "photon_pass": (2 * 80 * n_beams + 2 * 112 * n_segs) / (st["ms_emit"] * 1e-3) / 1e9 if st["ms_emit"] > 0 else None}}
+        ctx.close()
+        del frame
+        torch.cuda.empty_cache()
+        return out
 
     def run(self, name, steps, warmup, with_extras):
         """One workload: photon pass + LBVH (once, untimed), `warmup` + `steps` frames, the counted frame.
@@ -367,11 +429,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS) + sorted(BANDED))
     ap.add_argument("--cull", default="bins", choices=["bins", "lbvh", "scan"],
                     help="how a tile finds its candidate segments (default: screen-space bins)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only", action="store_true", help="measure --workload alone (no `other_workloads`)")
+    ap.add_argument("--no-banded", action="store_true", help="leave the banded workload (cfg5, about 15 s) out of `other_workloads`")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="one rank, but through the RCCL process group, the segment broadcast and the pipelined strip "
                          "gather of a job of several (a check of that code on one GPU; not the headline measurement)")
@@ -381,6 +444,13 @@ def main():
     args = ap.parse_args()
 
     b = Bench(args)
+    if args.workload in BANDED:       # on its own (profiling): not a headline line
+        if b.world != 1:
+            sys.exit("bench.py: the banded workloads run on one GPU")
+        r = b.run_banded(args.workload, min(args.steps, OTHER_STEPS[args.workload]), min(args.warmup, 1))
+        print(json.dumps(dict(r, metric="camera-ray x beam radiance queries/sec (Mray/s)", n_gpus=1)), flush=True)
+        b.close()
+        return
     head = b.run(args.workload, args.steps, args.warmup, with_extras=True)
     others = {}
     if not args.only:
@@ -394,6 +464,9 @@ def main():
                              "roofline_frac": r["roofline"]["frac"], "roofline_achieved": r["roofline"]["achieved"],
                              "flop_per_frame": r["roofline"]["flop_per_frame"], "flop_source": r["roofline"]["flop_source"],
                              "per_ray": r["per_ray"], "phases_ms": r["phases_ms"], "frame_ok": r["frame_ok"]}
+        if b.world == 1 and not args.no_banded:
+            for n in sorted(BANDED):
+                others[n] = b.run_banded(n, OTHER_STEPS[n], 1)
     if b.rank == 0:
         line = {"metric": "camera-ray x beam radiance queries/sec (Mray/s) at 512^2 Cornell box, 1-8 GPUs",
                 "value": head["value"], "unit": "Mray/s", "n_gpus": b.world, "steps": head["steps"], "warmup": head["warmup"],

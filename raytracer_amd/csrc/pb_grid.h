@@ -270,11 +270,12 @@ PB_DI float view_walk_mean(const GridView& g, const ViewWalk& w, V3 l, float s, 
   // one wait for the four loads: left to itself the compiler requests each where the sum needs it, four trips to memory
   // one after the other
   asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
-  const float px = 1.0f + l.x * s, py = 1.0f + l.y * s;
-  const float prop_x = fabsf(px - cell * cx) * rcell, prop_y = fabsf(py - cell * cy) * rcell;
-  const float left = c.x + ((c.y - c.x) * prop_y);
-  const float right = c.z + ((c.w - c.z) * prop_y);
-  const float e_end = fmaxf(left + ((right - left) * prop_x), 0.0f);
+  // (the relaxed estimator's own arithmetic: fused, where Extinction3D's restatement rounds every product)
+  const float px = __builtin_fmaf(l.x, s, 1.0f), py = __builtin_fmaf(l.y, s, 1.0f);
+  const float prop_x = fabsf(__builtin_fmaf(-cell, cx, px)) * rcell, prop_y = fabsf(__builtin_fmaf(-cell, cy, py)) * rcell;
+  const float left = __builtin_fmaf(c.y - c.x, prop_y, c.x);
+  const float right = __builtin_fmaf(c.w - c.z, prop_y, c.z);
+  const float e_end = fmaxf(__builtin_fmaf(right - left, prop_x, left), 0.0f);
   const float sum = w.e0 + t0 + t1 + t2 + e_end;
   return sum * __builtin_amdgcn_rcpf(n[0] + n[1] + n[2] + 2.0f);
 }

@@ -538,8 +538,11 @@ PB_DI int pair_het_fast_geometry(const float Rinv[9], float ox2, float oz2, floa
   if (!(a >= HET_FAST_MIN_SIN2)) return 3;
   const float sq = __builtin_amdgcn_sqrtf(b24ac);
   const float inv2a = fast_rcp(a + a);
-  const float t0 = (-b - sq) * inv2a;
-  const float t1 = (-b + sq) * inv2a;
+  // the roots about their mid-point (which the estimator needs anyway)
+  const float t_mid = -b * inv2a;
+  const float half = sq * inv2a;
+  const float t0 = t_mid - half;
+  const float t1 = t_mid + half;
   if (!((t0 > 0) && (t1 > t0))) return 1;
   const float dpy = __builtin_fmaf(Rinv[7], l.z, __builtin_fmaf(Rinv[4], l.y, Rinv[1] * l.x));
   const float y0 = __builtin_fmaf(t0, dpy, oy);
@@ -553,16 +556,16 @@ PB_DI int pair_het_fast_geometry(const float Rinv[9], float ox2, float oz2, floa
   const float q = -fast_rcp(dpy);
   const float thf = t0 + mul_zero_wins(y0 - fy, q);
   const float ths = t1 + mul_zero_wins(y1 - sy, q);
-  const float t_mid = -b * inv2a;
   tc_minus_out = thf * len;
   // The reference takes the view ray's direction from the entry and exit points it has rounded to float: over a chord
   // of relative length (ths - thf) / t_mid that direction is off by about 1e-7 t_mid / (ths - thf), which moves the
   // closest approach by that angle over sin^2(theta) - for a sliver of a segment far more than any fixed margin.
   const float noise = 2.5e-7f * t_mid * fast_rcp(fmaxf(ths - thf, 1e-30f) * a);
-  const float edge = fmaxf(HET_FAST_EDGE, noise) * t_mid + y_err * fabsf(q);
+  const float edge = __builtin_fmaf(fmaxf(HET_FAST_EDGE, noise), t_mid, y_err * fabsf(q));
   y_err_out = y_err + edge;                              // y moves by at most |dpy| <= 1 per unit of t
-  if (t_mid < thf - edge || t_mid > ths + edge) return 1;
-  if (t_mid < thf + edge || t_mid > ths - edge) return 3;
+  const float past_first = t_mid - thf, short_of_second = ths - t_mid;      // both positive inside the crossing
+  if (past_first < -edge || short_of_second < -edge) return 1;
+  if (past_first < edge || short_of_second < edge) return 3;
   t_mid_out = t_mid;
   y_star_out = __builtin_fmaf(t_mid, dpy, oy);
   sin2_out = a;
@@ -586,8 +589,10 @@ PB_DI void pair_het_fast_geometry_flat(const float Rinv[9], float ox2, float oz2
   const bool end_on = !(a >= HET_FAST_MIN_SIN2);
   const float sq = __builtin_amdgcn_sqrtf(b24ac);
   const float inv2a = fast_rcp(a + a);
-  const float t0 = (-b - sq) * inv2a;
-  const float t1 = (-b + sq) * inv2a;
+  const float t_mid = -b * inv2a;
+  const float half = sq * inv2a;
+  const float t0 = t_mid - half;
+  const float t1 = t_mid + half;
   const bool ordered = ((int)(t0 > 0) & (int)(t1 > t0)) != 0;
   const float dpy = __builtin_fmaf(Rinv[7], l.z, __builtin_fmaf(Rinv[4], l.y, Rinv[1] * l.x));
   const float y0 = __builtin_fmaf(t0, dpy, oy);
@@ -599,13 +604,13 @@ PB_DI void pair_het_fast_geometry_flat(const float Rinv[9], float ox2, float oz2
   const float q = -fast_rcp(dpy);
   const float thf = t0 + mul_zero_wins(y0 - fy, q);
   const float ths = t1 + mul_zero_wins(y1 - sy, q);
-  const float t_mid = -b * inv2a;
   tc_minus_out = thf * len;
   const float noise = 2.5e-7f * t_mid * fast_rcp(fmaxf(ths - thf, 1e-30f) * a);
-  const float edge = fmaxf(HET_FAST_EDGE, noise) * t_mid + y_err * fabsf(q);
+  const float edge = __builtin_fmaf(fmaxf(HET_FAST_EDGE, noise), t_mid, y_err * fabsf(q));
   y_err_out = y_err + edge;
-  const bool outside = ((int)(t_mid < thf - edge) | (int)(t_mid > ths + edge)) != 0;
-  const bool near = ((int)(t_mid < thf + edge) | (int)(t_mid > ths - edge)) != 0;
+  const float past_first = t_mid - thf, short_of_second = ths - t_mid;
+  const bool outside = ((int)(past_first < -edge) | (int)(short_of_second < -edge)) != 0;
+  const bool near = ((int)(past_first < edge) | (int)(short_of_second < edge)) != 0;
   const bool base = ((int)hit & (int)!end_on & (int)ordered & (int)in_caps & (int)!outside) != 0;
   ok_out = ((int)base & (int)!near) != 0;
   defer_out = ((int)hit & ((int)end_on | ((int)base & (int)near))) != 0;
