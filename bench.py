@@ -43,6 +43,7 @@ WORKLOADS = {
 BANDED = {"cfg5": dict(screen_width=4096, screen_height=4096, photon_number=1000000, bounces=3, heterogeneous=1,
                        one_dimensional=1, band_rows=512)}
 OTHER_STEPS = {"cfg1": 50, "cfg2": 50, "cfg3": 10, "cfg4": 10, "cfg5": 2}
+FRAMES_PER_GATHER = {"cfg1": 8, "cfg2": 2, "cfg3": 1, "cfg4": 1}     # jobs of several ranks: frames per strip all-gather
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 peak: 256 CUs x 4 SIMDs x 32 lanes x 2 (FMA) x 2.4 GHz
 STALL_SECONDS = 120        # a multi-rank run that stands still this long prints where and ends
 
@@ -72,7 +73,7 @@ def reference_pairs_flop(cnt, rays):
 def committed_profile(workload, cull, stamp):
     """The rocprofv3 counter passes committed for this workload (tools/profile_frame.py; rocprofv3 cannot
     run inside this process), if they were measured on the kernel sources this process runs."""
-    for rnd in ("r02",):
+    for rnd in ("r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload}.json")
         try:
             d = json.load(open(path))
@@ -296,7 +297,11 @@ class Bench:
         # ---- strips of this rank ----
         first_strip, strip_stride, n_my = tiles.strips_of_rank(H, rank, world)
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-        pipe = tiles.StripPipeline(world, n_my * 8, W, dev, frame=frame, timeout_s=STALL_SECONDS, exchange=self.exchange)
+        # frames whose strips share one collective: a 512^2 frame is shorter than a collective's enqueue on the host
+        fpg = args.frames_per_gather if args.frames_per_gather > 0 else (FRAMES_PER_GATHER.get(name, 1) if self.exchange else 1)
+        pipe = tiles.StripPipeline(world, n_my * 8, W, dev, frame=frame, timeout_s=STALL_SECONDS, exchange=self.exchange,
+                                   frames_per_gather=fpg)
+        fpg = pipe.K
         stream = torch.cuda.current_stream().cuda_stream
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -361,7 +366,12 @@ class Bench:
             prof, prof_path, prof_fresh = committed_profile(name, cull, stamp)
             alg = algorithmic_flop(cnt, rays)
             use_hw = bool(prof and prof_fresh and prof.get("fp32_flop_per_frame") and world == 1)
-            flop_frame = float(prof["fp32_flop_per_frame"]) if use_hw else alg
+            # Issued: 64 x the FP32 wave instructions the hardware counted.  Active: the same weighted, kernel by kernel,
+            # with the share of lanes the execution mask left on (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU): a wave
+            # instruction of which half the lanes are masked off does half the work.  `achieved` is the active figure.
+            issued_frame = float(prof["fp32_flop_per_frame"]) if use_hw else None
+            active_frame = float(prof["fp32_flop_active_lanes_per_frame"]) if (use_hw and prof.get("fp32_flop_active_lanes_per_frame")) else None
+            flop_frame = active_frame if active_frame else (issued_frame if issued_frame else alg)
             # one launch = this rank's share of the frame (the strips are interleaved, so 1 / world of the work)
             achieved = flop_frame / world / (kernel_ms * 1e-3) / 1e12
             frame_ok = bool(torch.isfinite(frame).all().item()) and float(frame.max().item()) > 0
@@ -370,19 +380,29 @@ class Bench:
                 "ms_per_step": dt / steps * 1e3,
                 "config": {"workload": f"{name}: Cornell box {W}x{H}, {wk['photon_number']} photons, BOUNCES {wk['bounces']}, "
                                        f"{'heterogeneous' if het else 'homogeneous'} medium, SEED 42 (GPU photon pass: "
-                                       f"{n_beams} beams, {n_segs} segments, own-box gate rule)",
+                                       f"{n_beams} beams, {n_segs} segments, own-box gate rule); primary rays and the radiance "
+                                       f"estimate every frame, with the binning schedule of the segment set (lists, survivors per "
+                                       f"tile, item queue) kept from its first frames as a tree would be",
                            "rays_per_frame": rays, "segments": n_segs, "cull": cull,
+                           "frames_per_gather": fpg if self.exchange else None,
                            "parallelism": f"row-strips x{world}" if world > 1 else
                                           ("single GPU, strips exchanged over RCCL as with several" if self.exchange else "single GPU")},
                 "roofline": {
                     "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_TFLOPS,
                     "traffic": float(prof["traffic_bytes"]) if (use_hw and prof.get("traffic_bytes")) else None,
-                    "kernel": "the frame's launches together (ray set-up + binning, evaluation, pixel write-out)",
+                    "kernel": "the frame's launches together: the kept-schedule frame is ray set-up then evaluation with the pixel "
+                              "write-out in it, or the evaluation alone where its items set up their own rays (cfg1)",
                     "kernel_ms": kernel_ms,
                     "kernel_ms_is": "HIP-event time of the timed region / steps: launches of a frame and the gaps between them",
                     "flop_per_frame": flop_frame,
-                    "flop_source": (f"hardware-counted: 64 x (ADD + MUL + 2 FMA + TRANS) FP32 wave instructions of the frame's kernels, "
+                    "issued": None if issued_frame is None else {
+                        "flop_per_frame": issued_frame, "tflops": issued_frame / world / (kernel_ms * 1e-3) / 1e12,
+                        "frac": issued_frame / world / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                        "note": "64 lanes x FP32 wave instructions, masked lanes included"},
+                    "lane_active_frac": (active_frame / issued_frame) if (active_frame and issued_frame) else None,
+                    "flop_source": (f"hardware-counted: 64 x (ADD + MUL + 2 FMA + TRANS) FP32 wave instructions of the frame's kernels"
+                                    f"{', each kernel weighted with its share of active lanes (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU)' if active_frame else ''}, "
                                     f"{prof_path} (measured on these kernel sources, stamp {stamp})") if use_hw else
                                    ("counted from this run's pairs: %g per ray + %g per evaluated pair + %g per cylinder hit + %g per "
                                     "valid hit (operations the kernels execute; a lower bound of the hardware count%s)" %
@@ -438,6 +458,8 @@ def main():
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="one rank, but through the RCCL process group, the segment broadcast and the pipelined strip "
                          "gather of a job of several (a check of that code on one GPU; not the headline measurement)")
+    ap.add_argument("--frames-per-gather", type=int, default=0,
+                    help="frames whose strips travel in one all-gather (jobs of several ranks; 0: per workload, 8 at cfg1)")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="frames kept in flight for the extra `pipelined` figure (0: skip it); `value` itself is always "
                          "measured one frame after the other on one stream")
@@ -463,7 +485,8 @@ def main():
                              "config": r["config"], "kernel_ms": r["roofline"]["kernel_ms"],
                              "roofline_frac": r["roofline"]["frac"], "roofline_achieved": r["roofline"]["achieved"],
                              "flop_per_frame": r["roofline"]["flop_per_frame"], "flop_source": r["roofline"]["flop_source"],
-                             "per_ray": r["per_ray"], "phases_ms": r["phases_ms"], "frame_ok": r["frame_ok"]}
+                             "per_ray": r["per_ray"], "phases_ms": r["phases_ms"], "frame_ok": r["frame_ok"],
+                             "roofline": r["roofline"], "phases_gb_per_s": r["phases_gb_per_s"]}
         if b.world == 1 and not args.no_banded:
             for n in sorted(BANDED):
                 others[n] = b.run_banded(n, OTHER_STEPS[n], 1)

@@ -68,6 +68,15 @@ def main():
     tiles.run_steps(pipe, frame, render, 25)
     torch.cuda.synchronize()
     assert torch.equal(frame, direct * 25.0)
+    # several frames to a collective (bench.py does that for frames this short): the last frame and every batch
+    pipe = tiles.StripPipeline(1, H, W, dev, frame=frame, timeout_s=60, exchange=True, frames_per_gather=4)
+    assert pipe.K == 4 and pipe.depth == 2
+    tiles.run_steps(pipe, frame, render, 22)            # five batches and a half
+    torch.cuda.synchronize()
+    assert torch.equal(frame, direct * 22.0), "batched gathers: last frame differs"
+    for slot, first in ((0, 16), (1, 20)):               # what the two slots last held: frames 16..19 and 20..21
+        for j in range(4 if slot == 0 else 2):
+            assert torch.equal(pipe.batch[slot][j], direct * float(first + j + 1)), f"batched frame {first + j} differs"
     ctx.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -60,6 +60,32 @@ def _worker(rank, world, port, height, width, out_dir):
                         40, on_step=steps_seen.append)
         assert steps_seen == list(range(40))
         assert np.array_equal(frame.numpy(), full * np.float32(2) + np.float32(39)), "run_steps: last frame differs"
+        # several frames per collective: frame k = full * 3 + k, seven to a gather (40 is no multiple: the last
+        # batch is cut short); every frame of a completed batch is in image order in pipe.batch, the last one in `frame`
+        K = 7
+        pipe = tiles.StripPipeline(world, n * 8, width, torch.device("cpu"), timeout_s=60, frames_per_gather=K)
+        batches = []
+
+        def render_k(mine, i):
+            mine.copy_(torch.from_numpy(full[rows] * np.float32(3) + np.float32(i)))
+        for i in range(40):
+            slot = pipe.begin(frame)
+            if i and i % K == 0:
+                pass
+            render_k(pipe.target(slot), i)
+            pipe.submit(slot)
+            if pipe.sent[slot] and pipe.depth == 1:
+                pipe._finish(slot, frame)             # completed here so that the batch can be looked at
+                batches.append(pipe.batch[slot].numpy().copy())
+        pipe.drain(frame)
+        assert np.array_equal(frame.numpy(), full * np.float32(3) + np.float32(39)), "batched: last frame differs"
+        assert len(batches) == 40 // K
+        for b, got in enumerate(batches):
+            for j in range(K):
+                assert np.array_equal(got[j], full * np.float32(3) + np.float32(b * K + j)), f"batched frame {b * K + j} differs"
+        pipe = tiles.StripPipeline(world, n * 8, width, torch.device("cpu"), timeout_s=60, frames_per_gather=4)
+        tiles.run_steps(pipe, frame, render_k, 10)
+        assert np.array_equal(frame.numpy(), full * np.float32(3) + np.float32(9)), "batched run_steps: last frame differs"
         # segment broadcast
         segs = None
         root = None
@@ -77,7 +103,7 @@ def _worker(rank, world, port, height, width, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_strips_gather_and_broadcast_over_gloo(world, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, 64, 40, str(tmp_path)), nprocs=world, join=True)
