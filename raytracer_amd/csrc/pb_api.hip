@@ -469,8 +469,11 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
         p.surv_list = ws.d_surv_list; p.kept_queue = 1;
       }
       // runs of 64 queue items per XCD: a tile's items share an L2 (cfg2: 91 -> 60 MB fetched by the evaluation, same
-      // time; 512^2 / 1000 photons 0.0447 -> 0.0420 ms); frames with very many items lose 2 % to it and deal singly
-      if (p.xcd_run < 0) p.xcd_run = p.n_items_host <= (1 << 17) ? 64 : 0;
+      // time; 512^2 / 1000 photons 0.0447 -> 0.0420 ms; longer runs leave XCDs idle at the end: cfg2 0.154 ms at 64, 0.160
+      // at 512, 0.170 at 1024).  A frame of very many items has rounds to spare: in runs of 4096 an XCD works through a
+      // few macro tiles at a time (1024^2, 100 000 photons, 186 000 items: 4.9 -> 3.4 GB through the fabric, L2 misses
+      // 3.2e7 -> 2.2e7 of 7.8e7 requests, 2.89 ms either way)
+      if (p.xcd_run < 0) p.xcd_run = p.n_items_host <= (1 << 17) ? 64 : 4096;
       // A frame of few items per tile is one launch: every item sets up its own rays (eval_items_fast_kernel's INLINE
       // form), which costs a tile's ray set-up once per item but saves the launch before the evaluation and the rays'
       // trip through memory.  The sums must have been left clear by the frame before (its last arrivers do that).

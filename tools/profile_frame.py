@@ -33,6 +33,7 @@ PASSES = {
              "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVES"],
     # share of a vector instruction's 64 lanes that the execution mask leaves on: thread-cycles over 64 x wave-cycles
     "lanes": ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INST_CYCLES_VALU", "SQ_INSTS_VALU"],
+    "l2": ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_READ_sum"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
 }
