@@ -640,7 +640,11 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   if (const char* e = std::getenv("PB_TUNE_XCDRUN")) { int v = std::atoi(e); if (v >= 0 && v <= 4096) p.xcd_run = v; }
   if (const char* e = std::getenv("PB_TUNE_WHOLE")) { int v = std::atoi(e); if (v >= 0 && v <= PB_SLICE) p.slice_whole = v; }
   p.eval_waves = ctx->tune_waves;
+#ifdef PB_EXPERIMENTS
+  // timing experiments that leave parts of a frame out (wrong frames): only in a library built with -DPB_EXPERIMENTS
+  // (make HIPFLAGS+=-DPB_EXPERIMENTS), never in the one that ships
   if (const char* e = std::getenv("PB_DEBUG_FLAGS")) p.debug = std::atoi(e);
+#endif
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
 

@@ -56,12 +56,17 @@ struct EmitParams {
   unsigned int* dropped;      // scattering events dropped because the stack was full
   GridView grid;              // extinction field; used when ctl.heterogeneous
   const pb_beam* sources;     // re-cast pass: the beams to cast again (one per lane instead of a photon)
-  int staged;                 // writing pass without a counting pass before it: every photon writes into EMIT_STAGE slots per
+  int staged;                 // > 0: writing pass without a counting pass before it: every photon writes into `staged` slots per
                               // list of its own in beams_const (= the staging buffer) and leaves its counts; gather_staged_kernel
                               // moves the beams to their places once the offsets are known
   unsigned int* overflow;     // staged pass: set when a photon pushed more beams into a list than it has slots for
 };
-constexpr int EMIT_STAGE = 16;                   // slots per photon and list of the staged pass
+// Slots per photon and list of the staged pass: what a photon can push grows with its bounces (one beam per bounce, and
+// one more per scattering event on the way, into the other list), so the slots are sized from the bounce budget - 80
+// bytes a slot, two lists: 640 B a photon without bounces, 2560 B at most.  A photon that outgrows them sends the whole
+// pass the two-pass way, so the count only decides how often that happens.
+constexpr int EMIT_STAGE_MAX = 16;
+PB_HDI int emit_stage_slots(int bounces) { const int want = 2 * (bounces + 1) + 2; return want < EMIT_STAGE_MAX ? want : EMIT_STAGE_MAX; }
 constexpr int EMIT_STAGE_MAX_PHOTONS = 1 << 18;  // 2 x 16 x 80 B per photon: 655 MB at most
 
 // CastPhotons.h:1128-1141
@@ -101,7 +106,7 @@ struct Frame {
 struct BeamSink {
   const EmitParams* p;
   uint32_t photon, order, n_const, n_scatt, off_const, off_scatt;
-  uint32_t cap;               // beams a list has room for at its offset (staged pass: EMIT_STAGE; else no limit)
+  uint32_t cap;               // beams a list has room for at its offset (staged pass: its slots; else no limit)
   bool scattered_only;        // re-cast pass: pushes into the first list are counted in `order` but not kept
 };
 
@@ -292,8 +297,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) 
   BeamSink sink;
   sink.p = &p; sink.photon = (uint32_t)i; sink.order = 0; sink.n_const = 0; sink.n_scatt = 0;
   const bool staged = WRITE && p.staged != 0;
-  sink.cap = staged ? (uint32_t)EMIT_STAGE : 0xffffffffu;
-  if (staged) { sink.off_const = (uint32_t)i * 2u * EMIT_STAGE; sink.off_scatt = sink.off_const + EMIT_STAGE; }
+  const uint32_t slots = (uint32_t)p.staged;
+  sink.cap = staged ? slots : 0xffffffffu;
+  if (staged) { sink.off_const = (uint32_t)i * 2u * slots; sink.off_scatt = sink.off_const + slots; }
   else {
     sink.off_const = (WRITE && !RECAST) ? p.off_const[i] : 0u;
     sink.off_scatt = WRITE ? p.off_scatt[i] : 0u;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) 
     f.bounce = 0; f.parity = 0; f.stage = 0; f.ada = (b.flags & 1u) != 0;
     cast_beam<WRITE>(p, rng, sink, f, v4(b.omega_u[0], b.omega_u[1], b.omega_u[2], b.omega_u[3]), b.radius);
     if (!WRITE || staged) { p.cnt_const[i] = 0u; p.cnt_scatt[i] = sink.n_scatt; }
-    if (staged && sink.n_scatt > (uint32_t)EMIT_STAGE) atomicOr(p.overflow, 1u);
+    if (staged && sink.n_scatt > slots) atomicOr(p.overflow, 1u);
     return;
   }
 
@@ -338,20 +344,20 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(const EmitParams p) 
   f.bounce = 0; f.parity = 0; f.stage = 0; f.ada = C.adaptive != 0;
   cast_beam<WRITE>(p, rng, sink, f, omega_u, r);
   if (!WRITE || staged) { p.cnt_const[i] = sink.n_const; p.cnt_scatt[i] = sink.n_scatt; }
-  if (staged && (sink.n_const > (uint32_t)EMIT_STAGE || sink.n_scatt > (uint32_t)EMIT_STAGE)) atomicOr(p.overflow, 1u);
+  if (staged && (sink.n_const > slots || sink.n_scatt > slots)) atomicOr(p.overflow, 1u);
 }
 
 // The beams of a staged pass to their places in the two lists: one lane per photon (or re-cast beam).
 __global__ __launch_bounds__(256) void gather_staged_kernel(const pb_beam* __restrict__ stage, const uint32_t* __restrict__ cnt_const,
                                                            const uint32_t* __restrict__ cnt_scatt, const uint32_t* __restrict__ off_const,
                                                            const uint32_t* __restrict__ off_scatt, pb_beam* __restrict__ beams_const,
-                                                           pb_beam* __restrict__ beams_scatt, int n) {
+                                                           pb_beam* __restrict__ beams_scatt, int n, int slots) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const pb_beam* mine = stage + (size_t)i * 2 * EMIT_STAGE;
+  const pb_beam* mine = stage + (size_t)i * 2 * slots;
   const uint32_t nc = cnt_const[i], ns = cnt_scatt[i];
   for (uint32_t k = 0; k < nc; ++k) beams_const[off_const[i] + k] = mine[k];
-  for (uint32_t k = 0; k < ns; ++k) beams_scatt[off_scatt[i] + k] = mine[EMIT_STAGE + k];
+  for (uint32_t k = 0; k < ns; ++k) beams_scatt[off_scatt[i] + k] = mine[slots + k];
 }
 
 // ---------------------------------------------------------------- segments --
@@ -561,12 +567,13 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   // to count and then to write, doubled it).  A photon that outgrows its slots sends the pass the two-pass way.
   const bool staged = n_photons > 0 && n_photons <= EMIT_STAGE_MAX_PHOTONS && !std::getenv("PB_TUNE_EMIT_TWICE");
   pb_beam* stage = nullptr;
+  const int stage_slots = emit_stage_slots(ctx->ctl.bounces);
   if (staged) {
     uint32_t* raw = nullptr;
-    rc = emit_scratch(ctx, 2, (sizeof(pb_beam) * 2 * EMIT_STAGE * n + sizeof(uint32_t) - 1) / sizeof(uint32_t), &raw);
+    rc = emit_scratch(ctx, 2, (sizeof(pb_beam) * 2 * stage_slots * n + sizeof(uint32_t) - 1) / sizeof(uint32_t), &raw);
     if (rc != PB_OK) return rc;
     stage = (pb_beam*)raw;
-    ep.staged = 1; ep.overflow = totals + 4;
+    ep.staged = stage_slots; ep.overflow = totals + 4;
     ep.beams_const = stage; ep.beams_scatt = stage;
     if (recast) hipLaunchKernelGGL((emit_kernel<true, true>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
     else hipLaunchKernelGGL((emit_kernel<true, false>), dim3(blocks), dim3(EMIT_THREADS), 0, s, ep);
@@ -602,7 +609,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   ep.beams_const = new_beams; ep.beams_scatt = new_beams + nc - listed_const;   // off_scatt counts the first list's beams
   if (staged && !h_overflow) {
     hipLaunchKernelGGL(gather_staged_kernel, dim3((n_photons + 255) / 256), dim3(256), 0, s, stage, cnt_const, cnt_scatt, off_const,
-                       off_scatt, ep.beams_const, ep.beams_scatt, n_photons);
+                       off_scatt, ep.beams_const, ep.beams_scatt, n_photons, stage_slots);
   } else if (n_photons > 0) {
     PB_HIP(hipMemsetAsync(totals + 3, 0, sizeof(uint32_t), s));   // the pass before this one reported the same drops
     ep.staged = 0;
