@@ -329,6 +329,18 @@ class Bench:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         kernel_ms = ev0.elapsed_time(ev1) / steps
+        # How much one timed region of `steps` frames scatters on this box: the same region four more times (not part
+        # of `value`, which is the region above and nothing else)
+        repeats = []
+        if with_extras and dt < 2.0:
+            for _ in range(4):
+                if self.exchange:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                tr = time.perf_counter()
+                tiles.run_steps(pipe, frame, render, steps, on_step=self.watchdog)
+                torch.cuda.synchronize()
+                repeats.append((time.perf_counter() - tr) / steps * 1e3)
         # The same frames with nothing kept from one to the next: counting pass, queue build, fill, evaluation and
         # pixel write-out every frame (the lists, their offsets and the item queue are functions of the segment set and
         # the frame geometry alone, and `value` is measured with them kept from the first frame, as a tree would be).
@@ -378,6 +390,7 @@ class Bench:
             out = {
                 "value": rays * steps / dt / 1e6, "unit": "Mray/s", "steps": steps, "warmup": warmup,
                 "ms_per_step": dt / steps * 1e3,
+                "repeats_ms_per_step": repeats if repeats else None,
                 "config": {"workload": f"{name}: Cornell box {W}x{H}, {wk['photon_number']} photons, BOUNCES {wk['bounces']}, "
                                        f"{'heterogeneous' if het else 'homogeneous'} medium, SEED 42 (GPU photon pass: "
                                        f"{n_beams} beams, {n_segs} segments, own-box gate rule); primary rays and the radiance "
