@@ -462,18 +462,34 @@ PB_DI int pair_721_fast_geometry(const float Rinv[9], float ox2, float oz2, floa
   return pair_721_fast_crossing(a, b, b24ac, v3(Rinv[1], Rinv[4], Rinv[7]), oy, len, tb0, r.l, extinction, log2_scale, tc_minus_out, value);
 }
 
+// The same with what is done with a valid crossing handed in as `then(tc_minus, value)`: called at the innermost point,
+// so that nothing the crossing computes has to be given a value on the paths that leave early (in the pair loop those
+// were eight register moves a step).
+template <class Then>
+PB_DI void pair_721_fast_crossing_then(float a, float b, float b24ac, V3 ry, float oy, float len, float tb0, V3 l,
+                                       float extinction, float log2_scale, Then&& then);
+
 PB_DI int pair_721_fast_crossing(float a, float b, float b24ac, V3 ry, float oy, float len, float tb0, V3 l,
                                  float extinction, float log2_scale, float& tc_minus_out, float& value) {
+  int res = 1;
+  pair_721_fast_crossing_then(a, b, b24ac, ry, oy, len, tb0, l, extinction, log2_scale,
+                              [&](float tc_minus, float v) { tc_minus_out = tc_minus; value = v; res = 2; });
+  return res;
+}
+
+template <class Then>
+PB_DI void pair_721_fast_crossing_then(float a, float b, float b24ac, V3 ry, float oy, float len, float tb0, V3 l,
+                                       float extinction, float log2_scale, Then&& then) {
   const float sq = __builtin_amdgcn_sqrtf(b24ac);
   const float inv2a = fast_rcp(a + a);
   const float t0 = (-b - sq) * inv2a;     // a > 0: already ordered, t0 <= t1
   const float t1 = (-b + sq) * inv2a;
-  if (!((t0 > 0) && (t1 > t0))) return 1;
+  if (!((t0 > 0) && (t1 > t0))) return;
   const float dpy = __builtin_fmaf(ry.z, l.z, __builtin_fmaf(ry.y, l.y, ry.x * l.x));
   const float y0 = __builtin_fmaf(t0, dpy, oy);
   const float y1 = __builtin_fmaf(t1, dpy, oy);
   const float y_low = fminf(y0, y1);
-  if (fmaxf(y0, y1) < 0.0f || y_low > 1.0f) return 1;               // passes below or above both caps
+  if (fmaxf(y0, y1) < 0.0f || y_low > 1.0f) return;                 // passes below or above both caps
   const float fy = __builtin_amdgcn_fmed3f(y0, 0.0f, 1.0f);         // y of the entry and exit points
   const float sy = __builtin_amdgcn_fmed3f(y1, 0.0f, 1.0f);
   const float q = -fast_rcp(dpy);                                   // (t1 - t0) / (y0 - y1); selected away where dpy == 0
@@ -482,7 +498,6 @@ PB_DI int pair_721_fast_crossing(float a, float b, float b24ac, V3 ry, float oy,
   const float ths = t1 + mul_zero_wins(y1 - sy, q);
   const float tc_minus = thf * len;
   const float tc_plus = ths * len;
-  tc_minus_out = tc_minus;
   const float chord = tc_plus - tc_minus;
   // tc- + tb- = len (th_first + min(fy, sy)) + tb0, and min(fy, sy) is the clamped min(y0, y1)
   const float reach = __builtin_fmaf(thf + __builtin_amdgcn_fmed3f(y_low, 0.0f, 1.0f), len, tb0);
@@ -493,8 +508,7 @@ PB_DI int pair_721_fast_crossing(float a, float b, float b24ac, V3 ry, float oy,
     phi = __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
   else phi = (__expf(x) - 1.0f) * fast_rcp(x);
   const float fall = __builtin_amdgcn_exp2f(__builtin_fmaf(reach, extinction * -1.44269504f, log2_scale));   // exp(-sigma_t (tc- + tb-))
-  value = chord * phi * fall;
-  return 2;
+  then(tc_minus, chord * phi * fall);
 }
 
 // The gate of a valid crossing: a segment whose gate box contains its cylinder (qflags bit 4) passes whenever the

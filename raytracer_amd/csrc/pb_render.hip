@@ -1387,27 +1387,35 @@ PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t 
   smem_load16(nxt, frames, off_nxt);
   SegHalfA a;
   __builtin_memcpy(&a, &cur, 64);
-  float tc_minus = 0.0f, value = 0.0f;
-  const int res = pair_721_fast_geometry(a.Rinv, a.ox2, a.oz2, a.c4, a.oy, a.len, a.tb0, r, extinction, -10.0f, tc_minus, value);
-  smem_wait(second, nxt);
-  SegHalfB b;
-  __builtin_memcpy(&b, &second, 64);
-  bool ok = res == 2;
-  if (ok && !pair_721_fast_sure(a.qflags, tc_minus, r.maxd)) ok = pair_721_fast_gate(b.lo, b.hi, b.cand, a.qflags, r);
-  if (ok) {
-    // carries the 2^-10 of the fixed-point sums; the median saturates a thin beam's 1/r^2 weight far above the
-    // display range and turns a NaN (degenerate record) into no contribution
-    const double integral = (double)__builtin_amdgcn_fmed3f(value, 0.0f, b.vcap10);
-    if (a.qflags & 64u) {
-      sum.ag += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
-      sum.ng++;
-    } else {
-      sum.ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
-      sum.ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[1], integral, PB_FIX_MAGIC));
-      sum.ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[2], integral, PB_FIX_MAGIC));
-      sum.nc++;
-    }
+  float qa, qb;
+  const float b24ac = pair_721_fast_quadratic(a.Rinv, a.ox2, a.oz2, a.c4, r.l, qa, qb);
+  if (!(b24ac < 0)) {
+    // what is done with a valid crossing sits at the innermost point of the pair's branches: nothing it needs has to
+    // be given a value on the paths that leave early
+    pair_721_fast_crossing_then(qa, qb, b24ac, v3(a.Rinv[1], a.Rinv[4], a.Rinv[7]), a.oy, a.len, a.tb0, r.l, extinction, -10.0f,
+                                [&](float tc_minus, float value) __attribute__((always_inline)) {
+      smem_wait(second);            // (only `second`: a scalar register written under a divergent branch must not live past it)
+      SegHalfB b;
+      __builtin_memcpy(&b, &second, 64);
+      bool ok = true;
+      if (!pair_721_fast_sure(a.qflags, tc_minus, r.maxd)) ok = pair_721_fast_gate(b.lo, b.hi, b.cand, a.qflags, r);
+      if (ok) {
+        // carries the 2^-10 of the fixed-point sums; the median saturates a thin beam's 1/r^2 weight far above the
+        // display range and turns a NaN (degenerate record) into no contribution
+        const double integral = (double)__builtin_amdgcn_fmed3f(value, 0.0f, b.vcap10);
+        if (a.qflags & 64u) {
+          sum.ag += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
+          sum.ng++;
+        } else {
+          sum.ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
+          sum.ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[1], integral, PB_FIX_MAGIC));
+          sum.ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[2], integral, PB_FIX_MAGIC));
+          sum.nc++;
+        }
+      }
+    });
   }
+  smem_wait(nxt);               // on every path (both loads have landed then): the next step reads `nxt`
 }
 
 // What an evaluation item does with its lane sums: adds them to its tile's accumulators and, where the frame has no
