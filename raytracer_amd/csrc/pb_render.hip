@@ -1403,14 +1403,16 @@ PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t 
         // carries the 2^-10 of the fixed-point sums; the median saturates a thin beam's 1/r^2 weight far above the
         // display range and turns a NaN (degenerate record) into no contribution
         const double integral = (double)__builtin_amdgcn_fmed3f(value, 0.0f, b.vcap10);
-        if (a.qflags & 64u) {
-          sum.ag += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
-          sum.ng++;
-        } else {
-          sum.ai[0] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
-          sum.ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[1], integral, PB_FIX_MAGIC));
-          sum.ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[2], integral, PB_FIX_MAGIC));
-          sum.nc++;
+        // Every term's first channel goes to the sum all channels share; a segment whose weights differ (its beam has
+        // met a coloured wall) adds, for the other two channels, what they have over the first - differences of two
+        // anchored terms, so they carry no anchor and need no count.  Integer arithmetic: the channels' sums are the
+        // same bits as with one sum per channel.  (One-sided: the common path joins nothing, so no value is moved.)
+        const unsigned long long first = (unsigned long long)__double_as_longlong(__builtin_fma(b.W[0], integral, PB_FIX_MAGIC));
+        sum.ag += first;
+        sum.ng++;
+        if (!(a.qflags & 64u)) {
+          sum.ai[1] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[1], integral, PB_FIX_MAGIC)) - first;
+          sum.ai[2] += (unsigned long long)__double_as_longlong(__builtin_fma(b.W[2], integral, PB_FIX_MAGIC)) - first;
         }
       }
     });
@@ -1585,6 +1587,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       off_cur = off2;
     }
     if (k < nb) pair_step(frames, ra, rb, off_cur, off_cur, r, extinction, sum);
+  }
+  {
+    // pair_step leaves the second and third channel as what they have over the first, the first in the common sum: as
+    // item_writeout takes them (a term count per plane, the anchors to subtract)
+    const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
+    sum.nc = (sum.ai[1] | sum.ai[2]) ? 1u : 0u;
+    sum.ai[0] = sum.nc ? magic_bits : 0ull; sum.ai[1] += sum.nc ? magic_bits : 0ull; sum.ai[2] += sum.nc ? magic_bits : 0ull;
   }
   item_writeout<FINALIZE>(p, tile, lane, sum);
 }
