@@ -347,6 +347,7 @@ class Bench:
         unkept_ms = None
         if world == 1 and with_extras and not self.exchange:
             os.environ["PB_TUNE_NO_KEEP"] = "1"
+            pb.reload_tuning()
             try:
                 tiles.run_steps(pipe, frame, render, max(2, warmup // 2))
                 torch.cuda.synchronize()
@@ -356,6 +357,7 @@ class Bench:
                 unkept_ms = (time.perf_counter() - t1) / max(10, steps // 2) * 1e3
             finally:
                 del os.environ["PB_TUNE_NO_KEEP"]
+                pb.reload_tuning()
             tiles.run_steps(pipe, frame, render, 2)      # the kept queue is in place again for what follows
             torch.cuda.synchronize()
         kt = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)

@@ -280,6 +280,10 @@ int pb_render_noalloc_d(pb_ctx* ctx, int x0, int y0, int w, int h, int mode, flo
  * end-on, a closest approach at a cap, a grid corner crossed by two axes at once) are evaluated in the reference's
  * order in double, as every pair is under 1 (about 2x slower).  Same tolerance. */
 int pb_set_precise(pb_ctx* ctx, int on);
+/* The PB_TUNE_* environment switches (experiments and diagnostics, none needed in use) are read
+ * when a context is created, never by a frame; a process that changes them while a context lives calls this to have
+ * them read again.  No counterpart in the reference (its switches are #defines, Control.h:4-31). */
+void pb_reload_tuning(void);
 
 /* PutPixelSDL (SDLauxiliary.h:149-161): RGB float -> 0x80RRGGBB, n pixels. */
 int pb_quantise_argb(const float* rgb, int n_pixels, uint32_t* argb_out);

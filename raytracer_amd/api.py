@@ -119,6 +119,7 @@ def library():
         L.pb_control_defaults.restype = None
         L.pb_transformation_matrix.restype = None
         L.pb_transform_points.restype = None
+        L.pb_reload_tuning.restype = None
         _lib = L
     return _lib
 
@@ -150,6 +151,11 @@ def control_defaults(**over):
         else:
             setattr(c, k, v)
     return c
+
+
+def reload_tuning():
+    """Have the library read the PB_TUNE_* environment switches again (it reads them when a context is created)."""
+    library().pb_reload_tuning()
 
 
 def device_count():

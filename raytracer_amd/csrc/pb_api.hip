@@ -101,6 +101,38 @@ int static_workspace_init(int device) {
 
 }  // namespace
 
+namespace {
+PbTune g_tune;
+std::once_flag g_tune_once;
+int env_int(const char* name, int unset) { const char* e = std::getenv(name); return e ? std::atoi(e) : unset; }
+}  // namespace
+
+void pb_tune_reload() {
+  PbTune t;
+  t.surv = env_int("PB_TUNE_SURV", -1); t.fused_max = env_int("PB_TUNE_FUSED_MAX", -1);
+  t.macrow = env_int("PB_TUNE_MACROW", -1); t.macroh = env_int("PB_TUNE_MACROH", -1);
+  t.xcdrun = env_int("PB_TUNE_XCDRUN", -1); t.whole = env_int("PB_TUNE_WHOLE", -1);
+  t.slice = env_int("PB_TUNE_SLICE", -1); t.waves = env_int("PB_TUNE_WAVES", -1); t.raywaves = env_int("PB_TUNE_RAYWAVES", -1);
+#ifdef PB_EXPERIMENTS
+  // timing experiments that leave parts of a frame out (wrong frames): only in a library built with -DPB_EXPERIMENTS
+  // (make HIPFLAGS+=-DPB_EXPERIMENTS), never in the one that ships
+  t.debug = env_int("PB_DEBUG_FLAGS", 0);
+#endif
+  if (const char* e = std::getenv("PB_TUNE_INLINE")) t.inline_ratio = std::atof(e);
+  t.no_prefine = std::getenv("PB_TUNE_NO_PREFINE") != nullptr; t.no_keep = std::getenv("PB_TUNE_NO_KEEP") != nullptr;
+  t.separate_finalize = std::getenv("PB_SEPARATE_FINALIZE") != nullptr; t.refill = std::getenv("PB_TUNE_REFILL") != nullptr;
+  t.debug_times = std::getenv("PB_DEBUG_TIMES") != nullptr; t.emit_twice = std::getenv("PB_TUNE_EMIT_TWICE") != nullptr;
+  t.het1 = std::getenv("PB_TUNE_HET1") != nullptr; t.het2 = std::getenv("PB_TUNE_HET2") != nullptr;
+  t.old_eval = std::getenv("PB_OLD_EVAL") != nullptr; t.no_residue = std::getenv("PB_TUNE_NO_RESIDUE") != nullptr;
+  t.wide = std::getenv("PB_TUNE_WIDE") != nullptr;
+  g_tune = t;
+}
+
+const PbTune& pb_tune() {
+  std::call_once(g_tune_once, pb_tune_reload);
+  return g_tune;
+}
+
 int pb_ensure_segment_capacity(pb_ctx* ctx, int n) {
   if (n <= ctx->cap_seg) return PB_OK;
   int cap = n + n / 8 + 64;
@@ -310,7 +342,7 @@ int build_survivor_lists(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int m
   if (p.strip_stride > 1) length = length / 2 < 16 ? 16 : length / 2;       // a rank's share of the strips: fewer items
   // an item's survivors must fit the LDS list of whichever kernel evaluates it
   const int most = pb_max_item_survivors();
-  if (const char* e = std::getenv("PB_TUNE_SURV")) { int v = std::atoi(e); if (v >= 1) length = v; }
+  if (pb_tune().surv >= 1) length = pb_tune().surv;
   if (length > most) length = most;
   PB_HIP(hipMemsetAsync(regroup_cnt, 0, sizeof(uint32_t) * (size_t)slots, s));
   rc = pb_launch_regroup_items(p, false, n_old, length, regroup_cnt, nullptr, s);
@@ -353,12 +385,12 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
   // each segment's own rectangle of macro tiles).  The two ways fill the lists by different (conservative) tests, so
   // what was sized for one says nothing about the other: the limit is part of the key.
   int fused_max_seg = 1 << 20;
-  if (const char* e = std::getenv("PB_TUNE_FUSED_MAX")) { int v = std::atoi(e); if (v >= 0) fused_max_seg = v; }
+  if (pb_tune().fused_max >= 0) fused_max_seg = pb_tune().fused_max;
   unsigned long long key[6];
   std::memcpy(key, key_in, sizeof(key));
   key[4] |= ((unsigned long long)(uint32_t)fused_max_seg + 1ull) << 8;
   // whether the kept queue's items hold survivors (build_survivor_lists) or candidates is part of what is kept
-  const bool keep_survivors = !ws.fixed && !std::getenv("PB_TUNE_NO_PREFINE");
+  const bool keep_survivors = !ws.fixed && !pb_tune().no_prefine;
   key[4] |= (keep_survivors ? 1ull : 0ull) << 48;
   const int tiles = p.tiles_x * p.tiles_y;
   const int groups = tiles * p.ssaa * p.ssaa;
@@ -392,10 +424,10 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
     // With interleaved strips a macro tile takes fewer tile rows: eight would span strip_stride times the
     // height on screen and hand every tile the segments of a whole column to refine.
     p.macro_w = PB_MACRO;
-    if (const char* e = std::getenv("PB_TUNE_MACROW")) { int v = std::atoi(e); if (v >= 1 && v <= PB_MACRO) p.macro_w = v; }
+    if (pb_tune().macrow >= 1 && pb_tune().macrow <= PB_MACRO) p.macro_w = pb_tune().macrow;
     p.macro_h = p.macro_w / p.strip_stride;     // keeps a macro tile's footprint square on screen
     if (p.macro_h < 1) p.macro_h = 1;
-    if (const char* e = std::getenv("PB_TUNE_MACROH")) { int v = std::atoi(e); if (v >= 1 && v <= PB_MACRO) p.macro_h = v; }
+    if (pb_tune().macroh >= 1 && pb_tune().macroh <= PB_MACRO) p.macro_h = pb_tune().macroh;
     const int mtiles = pb_macro_count(p);
     const int slots = mtiles * p.macro_w * p.macro_h;     // queue slots: every macro tile has room for all its tiles
     rc = ensure_bin_workspace(ws, slots, want_bins, want_items, px);
@@ -447,18 +479,18 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       p.blk = ws.d_blk;
     }
     if (ctx->count_on || ctx->time_render) PB_HIP(hipEventRecord(ctx->ev[0], s));
-    if (verified && ws.queue_kept && p.fused_queue && !ctx->count_on && p.n_seg > 0 && !std::getenv("PB_TUNE_NO_KEEP")) {
+    if (verified && ws.queue_kept && p.fused_queue && !ctx->count_on && p.n_seg > 0 && !pb_tune().no_keep) {
       // The lists, their offsets and the item queue are functions of the segment set and the frame geometry alone and are
       // in the workspace from the frame that sized it for this key (as a tree would be kept): ray set-up, evaluation,
       // pixels.  PB_TUNE_REFILL fills the lists again every frame (the binning pass beside the ray set-up).
       p.n_items_host = ws.ws_items_needed;
-      p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !pb_residue_frame(p, mode) && !std::getenv("PB_SEPARATE_FINALIZE")) ? 1 : 0;
+      p.finalize_in_eval = (pb_pipelined_eval(p, mode) && !pb_residue_frame(p, mode) && !pb_tune().separate_finalize) ? 1 : 0;
       bool made_now = false;
       if (!ws.surv_ready && keep_survivors) {
         // the first kept frame of this queue: it also tests every item's candidates once and for all and cuts the
         // queue anew by survivors; its ray set-up runs first (the tests read the tiles' planes from the ray blocks and
         // group_last), against the per-tile item counts of the queue as built
-        rc = pb_launch_fast_frame(p, mode, !std::getenv("PB_TUNE_REFILL"), s, 1);
+        rc = pb_launch_fast_frame(p, mode, !pb_tune().refill, s, 1);
         if (rc != PB_OK) return rc;
         rc = build_survivor_lists(ctx, ws, p, mode, slots, s);
         if (rc != PB_OK) return rc;
@@ -478,7 +510,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       // form), which costs a tile's ray set-up once per item but saves the launch before the evaluation and the rays'
       // trip through memory.  The sums must have been left clear by the frame before (its last arrivers do that).
       double inline_ratio = 4.0;
-      if (const char* e = std::getenv("PB_TUNE_INLINE")) inline_ratio = std::atof(e);
+      if (pb_tune().inline_ratio >= 0.0) inline_ratio = pb_tune().inline_ratio;
       const bool one_launch = ws.surv_ready && !made_now && ws.sums_left_clear && mode == PB_MODE_721 && p.finalize_in_eval &&
                               pb_pipelined_eval(p, mode) && !ctx->ctl.short_view &&
                               (double)p.n_items_host <= inline_ratio * (double)groups;
@@ -495,7 +527,7 @@ int render_binned(pb_ctx* ctx, FrameWorkspace& ws, RenderParams& p, int mode, co
       else if (keep_survivors && !ws.surv_ready) {       // the lists could not be made: stage 1 has run
         rc = pb_launch_fast_frame(p, mode, true, s, 2);
       }
-      else rc = pb_launch_fast_frame(p, mode, !std::getenv("PB_TUNE_REFILL"), s);
+      else rc = pb_launch_fast_frame(p, mode, !pb_tune().refill, s);
       if (rc != PB_OK) return rc;
       ws.sums_left_clear = mode == PB_MODE_721 && p.finalize_in_eval && pb_pipelined_eval(p, mode);
       if (ctx->count_on || ctx->time_render) { PB_HIP(hipEventRecord(ctx->ev[1], s)); ctx->ev_valid[0] = true; }
@@ -637,14 +669,10 @@ int render_common(pb_ctx* ctx, FrameWorkspace& ws, int x0, int y0, int out_w, in
   p.slice = ctx->tune_slice > 0 ? ctx->tune_slice : (strip_stride > 1 ? 96 : 128);   // render_binned refines it per frame geometry
   p.slice_whole = 0;
   p.xcd_run = -1;           // chosen with the item count in render_binned
-  if (const char* e = std::getenv("PB_TUNE_XCDRUN")) { int v = std::atoi(e); if (v >= 0 && v <= 4096) p.xcd_run = v; }
-  if (const char* e = std::getenv("PB_TUNE_WHOLE")) { int v = std::atoi(e); if (v >= 0 && v <= PB_SLICE) p.slice_whole = v; }
+  if (pb_tune().xcdrun >= 0 && pb_tune().xcdrun <= 4096) p.xcd_run = pb_tune().xcdrun;
+  if (pb_tune().whole >= 0 && pb_tune().whole <= PB_SLICE) p.slice_whole = pb_tune().whole;
   p.eval_waves = ctx->tune_waves;
-#ifdef PB_EXPERIMENTS
-  // timing experiments that leave parts of a frame out (wrong frames): only in a library built with -DPB_EXPERIMENTS
-  // (make HIPFLAGS+=-DPB_EXPERIMENTS), never in the one that ships
-  if (const char* e = std::getenv("PB_DEBUG_FLAGS")) p.debug = std::atoi(e);
-#endif
+  p.debug = pb_tune().debug;          // 0 unless the library was built with -DPB_EXPERIMENTS
   p.counters = ctx->count_on ? ctx->d_counters : nullptr;
   if (ctx->count_on) PB_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * PB_CNT_N, s));
 
@@ -750,8 +778,9 @@ int pb_create(const pb_control* control, int device, pb_ctx** out) {
   };
   const int rc_set_up = set_up();
   if (rc_set_up != PB_OK) { pb_destroy(ctx); return rc_set_up; }      // releases whatever was created
-  if (const char* e = std::getenv("PB_TUNE_SLICE")) { int v = std::atoi(e); if (v >= 32 && v <= PB_SLICE) ctx->tune_slice = v; }
-  if (const char* e = std::getenv("PB_TUNE_WAVES")) { int v = std::atoi(e); if (v == 0 || (v >= 64 && v <= (1 << 20))) ctx->tune_waves = v; }
+  pb_tune_reload();                   // a context created after the environment changed sees the change
+  { const int v = pb_tune().slice; if (v >= 32 && v <= PB_SLICE) ctx->tune_slice = v; }
+  { const int v = pb_tune().waves; if (v == 0 || (v >= 64 && v <= (1 << 20))) ctx->tune_waves = v; }
   *out = ctx;
   return PB_OK;
 }
@@ -1077,6 +1106,8 @@ int pb_quantise_argb(const float* rgb, int n_pixels, uint32_t* argb_out) {
   return PB_OK;
 }
 
+void pb_reload_tuning(void) { pb_tune_reload(); }
+
 int pb_set_precise(pb_ctx* ctx, int on) {
   if (!ctx) { pb_set_error("pb_set_precise: null context"); return PB_ERR_ARG; }
   ctx->precise = on != 0;
@@ -1106,7 +1137,7 @@ int pb_counters(pb_ctx* ctx, pb_stats* out) {
   ctx->stats.valid_hits = h[PB_CNT_VALID]; ctx->stats.nodes_visited = h[PB_CNT_NODES];
   ctx->stats.gate_passes = h[PB_CNT_GATED];
   ctx->stats.shortcut_wrong = h[PB_CNT_SHORTCUT_WRONG];
-  if (std::getenv("PB_DEBUG_TIMES") && h[PB_CNT_T_END]) {
+  if (pb_tune().debug_times && h[PB_CNT_T_END]) {
     const double t0 = (double)~h[PB_CNT_T_START_INV], td = (double)~h[PB_CNT_T_DRAIN_INV], te = (double)h[PB_CNT_T_END];
     std::fprintf(stderr, "[pb] evaluation queue: %llu items, first wave leaves the empty queue at %.1f us, last wave ends at %.1f us\n",
                  (unsigned long long)h[PB_CNT_ITEMS], (td - t0) * 0.01, (te - t0) * 0.01);

@@ -565,7 +565,7 @@ int pb_emit_run(pb_ctx* ctx, int n_photons, uint64_t seed, bool recast) {
   // Up to EMIT_STAGE_MAX_PHOTONS photons the beams are cast once, into slots of the photon's own, and moved when the
   // offsets are known (the photon pass of a small set is one long chain of dependent steps per lane; casting twice,
   // to count and then to write, doubled it).  A photon that outgrows its slots sends the pass the two-pass way.
-  const bool staged = n_photons > 0 && n_photons <= EMIT_STAGE_MAX_PHOTONS && !std::getenv("PB_TUNE_EMIT_TWICE");
+  const bool staged = n_photons > 0 && n_photons <= EMIT_STAGE_MAX_PHOTONS && !pb_tune().emit_twice;
   pb_beam* stage = nullptr;
   const int stage_slots = emit_stage_slots(ctx->ctl.bounces);
   if (staged) {

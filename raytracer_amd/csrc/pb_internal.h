@@ -256,6 +256,17 @@ struct FrameWorkspace {
 
 void pb_set_error(const std::string& msg);
 
+// The PB_TUNE_* / PB_DEBUG_* switches (diagnostics and experiments; none is needed in use), read from the environment
+// when the first context is created and again by every pb_create and pb_reload_tuning - never by a frame.
+struct PbTune {
+  int surv = -1, fused_max = -1, macrow = -1, macroh = -1, xcdrun = -1, whole = -1, slice = -1, waves = -1, raywaves = -1, debug = 0;
+  double inline_ratio = -1.0;
+  bool no_prefine = false, no_keep = false, separate_finalize = false, refill = false, debug_times = false, emit_twice = false,
+       het1 = false, het2 = false, old_eval = false, no_residue = false, wide = false;
+};
+const PbTune& pb_tune();
+void pb_tune_reload();
+
 // One GPU's state (opaque to callers of the C ABI).
 struct pb_ctx {
   pb_control ctl;

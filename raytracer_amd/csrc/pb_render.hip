@@ -2428,12 +2428,12 @@ static bool wide_records(const RenderParams& p) { return (size_t)p.n_seg * sizeo
 // the 23.7 M segments (4.5 GB of records) of the largest configuration, whose frame is mostly the cone, the one-pass
 // kernel is faster (2.85 against 3.43 s).  PB_TUNE_HET1 / PB_TUNE_HET2 force one or the other.
 static bool het_two_pass(const RenderParams& p) {
-  if (std::getenv("PB_TUNE_HET1") || p.n_seg >= (1 << 25)) return false;     // its queue keys: 25 bits of segment, 6 of ray, 1 flag
+  if (pb_tune().het1 || p.n_seg >= (1 << 25)) return false;     // its queue keys: 25 bits of segment, 6 of ray, 1 flag
   if (p.slice > HET2_SLICE) return false;                                      // its survivor list in LDS
-  return !wide_records(p) || std::getenv("PB_TUNE_HET2") != nullptr;
+  return !wide_records(p) || pb_tune().het2;
 }
 bool pb_pipelined_eval(const RenderParams& p, int mode) {
-  if (p.precise || p.eval_waves > 0 || std::getenv("PB_OLD_EVAL")) return false;
+  if (p.precise || p.eval_waves > 0 || pb_tune().old_eval) return false;
   if (mode == PB_MODE_721) return !wide_records(p);
   // eval_items_het_kernel addresses records beyond 2 GB by their own 64-bit addresses (its WIDE form)
   // eval_items_het_kernel: its walk tables hold the crossings of a grid of at most VIEW_WALK_MAX_SIDE points a side
@@ -2444,7 +2444,7 @@ bool pb_pipelined_eval(const RenderParams& p, int mode) {
 
 bool pb_residue_frame(const RenderParams& p, int mode) {
   return (mode == PB_MODE_73 || mode == PB_MODE_73HET) && p.residue && pb_pipelined_eval(p, mode) && het_two_pass(p) &&
-         !std::getenv("PB_TUNE_NO_RESIDUE");
+         !pb_tune().no_residue;
 }
 
 int pb_launch_cull(const RenderParams& p, int mode, bool count, hipStream_t s) {
@@ -2553,7 +2553,7 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
     else if (pb_pipelined_eval(p, mode)) {
       if (p.grid_z) hipLaunchKernelGGL(view_walk_kernel, dim3(p.tiles_x * p.tiles_y * p.ssaa * p.ssaa), dim3(64), 0, s, p);
       if (p.xcd_run > 0) waves = (waves + 8 * p.xcd_run - 1) / (8 * p.xcd_run) * (8 * p.xcd_run);    // whole runs for every XCD
-      const bool wide = wide_records(p) || std::getenv("PB_TUNE_WIDE") != nullptr;
+      const bool wide = wide_records(p) || pb_tune().wide;
       const bool two_pass = het_two_pass(p);
       if (pb_residue_frame(p, mode)) {
         // the items hand the pairs they leave to the exact-order code to one more launch; the pixels are written after it
@@ -2658,7 +2658,7 @@ int pb_launch_fast_frame(const RenderParams& p, int mode, bool lists_in_place, h
     // ray set-up alone: blocks of eight waves (512^2, 1052 segments: 0.0392 ms a frame with one wave to a block, 0.0386
     // with two, 0.0380 with four, 0.0375 with eight, 0.0378 with sixteen; a block stages the scene in LDS once)
     int waves = 8;
-    if (const char* e = std::getenv("PB_TUNE_RAYWAVES")) waves = std::atoi(e);
+    if (pb_tune().raywaves > 0) waves = pb_tune().raywaves;
     if (waves == 4) hipLaunchKernelGGL(setup_rays_kernel<256>, dim3((groups + 3) / 4), dim3(256), lds, s, p, groups, scene_in_lds);
     else if (waves == 16) hipLaunchKernelGGL(setup_rays_kernel<1024>, dim3((groups + 15) / 16), dim3(1024), lds, s, p, groups, scene_in_lds);
     else hipLaunchKernelGGL(setup_rays_kernel<512>, dim3((groups + 7) / 8), dim3(512), lds, s, p, groups, scene_in_lds);

@@ -179,11 +179,13 @@ def test_het_render_matches_oracle(pb):
         for env in (dict(PB_TUNE_WIDE="1"), dict(PB_TUNE_WIDE="1", PB_TUNE_FUSED_MAX="0"), dict(PB_TUNE_NO_RESIDUE="1"),
                     dict(PB_TUNE_HET1="1"), dict(PB_TUNE_HET1="1", PB_TUNE_WIDE="1")):
             os.environ.update(env)
+            pb.reload_tuning()
             try:
                 wide.extend(ctx.draw(mode=pb.MODE_73HET, cull="bins") for _ in range(2))
             finally:
                 for k in env:
                     del os.environ[k]
+                pb.reload_tuning()
         ctx.set_precise(True)                                                   # the reference's operation order
         bins = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)
         bins2 = ctx.draw(mode=pb.MODE_73HET, cull="bins")

@@ -438,6 +438,7 @@ def test_repeated_frames_of_one_segment_set_are_bit_identical(pb, kw):
         # schedule_rebuilt_every_frame), then kept again
         import os
         os.environ["PB_TUNE_NO_KEEP"] = "1"
+        pb.reload_tuning()
         try:
             for _ in range(3):
                 ctx.draw_device(out.data_ptr(), 0, 0, W, H, cull="bins", stream=stream)
@@ -445,12 +446,14 @@ def test_repeated_frames_of_one_segment_set_are_bit_identical(pb, kw):
             assert np.array_equal(out.cpu().numpy(), first)
         finally:
             del os.environ["PB_TUNE_NO_KEEP"]
+            pb.reload_tuning()
         out.fill_(-1.0)
         ctx.draw_device(out.data_ptr(), 0, 0, W, H, cull="bins", stream=stream)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), first)
         # the lists filled again every frame beside the ray set-up (PB_TUNE_REFILL), then kept again
         os.environ["PB_TUNE_REFILL"] = "1"
+        pb.reload_tuning()
         try:
             for _ in range(2):
                 out.fill_(-1.0)
@@ -459,6 +462,7 @@ def test_repeated_frames_of_one_segment_set_are_bit_identical(pb, kw):
             assert np.array_equal(out.cpu().numpy(), first)
         finally:
             del os.environ["PB_TUNE_REFILL"]
+            pb.reload_tuning()
         # a new segment set in the same context and geometry: nothing of the old lists may survive
         ctx.cast_photon_beams(seed=7)
         other = ctx.draw(cull="bins")
@@ -493,6 +497,7 @@ def test_both_binning_passes_give_the_same_frame(pb, het, monkeypatch):
             else:
                 monkeypatch.delenv("PB_TUNE_FUSED_MAX", raising=False)
             assert os.environ.get("PB_TUNE_FUSED_MAX", "") == limit
+            pb.reload_tuning()             # the switches are read when a context is created, not by its frames
             frames.setdefault(limit, []).extend(ctx.draw(mode=mode, cull="bins") for _ in range(2))
     ref = frames[""][0]
     assert ref.max() > 0.05 and np.isfinite(ref).all()

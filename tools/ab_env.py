@@ -28,6 +28,7 @@ for name in names:
             for which in ("off", "on"):
                 if which == "on": os.environ[var] = val
                 else: os.environ.pop(var, None)
+                pb.reload_tuning()
                 for _ in range(5):
                     ctx.draw_device(out.data_ptr(), 0, 0, W, H, mode=mode, cull="bins", stream=stream)
                 torch.cuda.synchronize()

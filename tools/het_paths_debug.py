@@ -6,9 +6,10 @@ kw = dict(photon_number=600, bounces=1, screen_width=256, screen_height=256, het
 ctx = pb.Context(pb.control_defaults(**kw))
 ctx.set_scene(); ctx.set_grid(*pb.make_grid()); ctx.cast_photon_beams()
 def frames(env, n=3):
-    os.environ.update(env)
+    os.environ.update(env); pb.reload_tuning()
     out = [ctx.draw(mode=pb.MODE_73HET, cull="bins") for _ in range(n)]
     for k in env: del os.environ[k]
+    pb.reload_tuning()
     return out
 ctx.set_precise(True)
 exact = ctx.draw(mode=pb.MODE_73HET, cull="bins").astype(np.float64)
