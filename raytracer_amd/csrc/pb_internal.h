@@ -32,7 +32,7 @@ static_assert(sizeof(TriPrep) == 64, "TriPrep layout");
 // gate box and the radiance weight.  48 dwords = 192 B, 64-byte aligned so a
 // wave-uniform record is fetched with s_load_dwordx16.  The first 32 dwords are
 // all the default (fast) pair evaluation reads: two loads, one round trip.
-struct __attribute__((aligned(64))) SegFrame {
+struct __attribute__((aligned(256))) SegFrame {
   float Rinv[9];   //  0.. 8  R_inv, m[col][row] at col*3+row
   float ox2, oz2;  //  9,10   2*T_inv.x, 2*T_inv.z
   float c4;        // 11      4*c, c of Intersections.h:344-346
@@ -53,8 +53,11 @@ struct __attribute__((aligned(64))) SegFrame {
   float bdir[3];   // 43..45  normalize(end-start)
   float radius;    // 46
   float ymin;      // 47      cone records: y of seg.start in the cone's frame (Intersections.h:175); else 0
+  float pad[16];   // 48..63  a record is two 128-byte L2 lines of its own: the halves the pair loop fetches (dwords 0..15 and
+                   //         16..31, two scalar loads) always share the first one - at 192 bytes every other record straddled two
 };
-static_assert(sizeof(SegFrame) == 192, "SegFrame layout");
+static_assert(sizeof(SegFrame) == 256, "SegFrame layout");
+constexpr int PB_FRAME_USED_BYTES = 192;
 
 // What Integral_73Het (BeamRadiance.h:211-288) reads of a segment beyond its end points: 8 dwords.
 struct __attribute__((aligned(32))) HetFrame {

@@ -1698,7 +1698,7 @@ PB_DI SegFrame load_frame_wide(const SegFrame* src) {
   const uint4* s4 = (const uint4*)src;
   uint4* d4 = (uint4*)&f;
 #pragma unroll
-  for (int i = 0; i < (int)(sizeof(SegFrame) / 16); ++i) d4[i] = s4[i];
+  for (int i = 0; i < PB_FRAME_USED_BYTES / 16; ++i) d4[i] = s4[i];
   return f;
 }
 
