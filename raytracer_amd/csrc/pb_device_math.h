@@ -22,6 +22,19 @@ template <class T>
 __device__ __forceinline__ const PB_CONST_AS T* pb_uniform(const T* p) {
   return (const PB_CONST_AS T*)(p);
 }
+// The argument block of a kernel whose only parameter is a T by value, as a pointer the compiler has to load through
+// again: code that runs rarely inside a hot loop reads its arguments this way (a scalar load when it runs) rather than
+// from scalar registers held, or spilled into vector lanes and restored, across every turn of the loop.
+template <class T>
+__device__ __forceinline__ const PB_CONST_AS T* kernarg_again() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const PB_CONST_AS T* q = (const PB_CONST_AS T*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return q;
+#else
+  return nullptr;
+#endif
+}
 #define PB_HDI __host__ __device__ __forceinline__
 
 struct V3 { float x, y, z; };

@@ -1856,9 +1856,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     }
     pending += __builtin_popcountll(mask);
   };
+  // (the drain takes what it needs of the kernel's arguments from the argument block again, kernarg_again, instead of
+  // from scalar registers that would stay occupied across the survivor loop)
   auto drain = [&](int take) {
     __syncthreads();
     if (lane < take) {
+      const PB_CONST_AS RenderParams* q = kernarg_again<RenderParams>();
+      const float* rr = q->rays + (size_t)group * PB_RAY_WORDS * 64;
+      GridView grid;
+      grid.z = q->grid_z; grid.side = q->grid_side; grid.fast_div = q->grid_fast_div;
       const int e = pending - take + lane;
       const uint32_t sidx = q_seg[e], rl = q_ray[e];
       Ray rq;
@@ -1867,11 +1873,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
       rq.maxd = rr[6 * 64 + rl];
       rq.d1 = v3(rr[8 * 64 + rl], rr[9 * 64 + rl], rr[10 * 64 + rl]);
       rq.active = true;
-      const SegFrame f = load_frame_wide(p.frames + sidx);
+      const SegFrame f = load_frame_wide(q->frames + sidx);
       CylHit hit;
       if (hit_cylinder_exact(f, rq, hit) == 2) {
-        const float4 A = p.capA[sidx];
-        double integral = integral_73het(h.grid, v3(A.x, A.y, A.z), p.het[sidx], p.het_axis[sidx], hit, rq, p.extinction_c, p.scattering_c);
+        const float4 A = q->capA[sidx];
+        double integral = integral_73het(grid, v3(A.x, A.y, A.z), q->het[sidx], q->het_axis[sidx], hit, rq, q->extinction_c, q->scattering_c);
         const double W0 = f.W[0], W1 = f.W[1], W2 = f.W[2];
         integral = fmin(integral, PB_FIX_LIMIT / fmax(W0, fmax(W1, W2)));
         integral = integral * PB_FIX_PRESCALE;
@@ -1982,18 +1988,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   int ns = refine_candidates<true>(p, start, cn, pl, surv, lane, it[3]);
   s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull; s_acc[3][lane] = 0ull;
   __syncthreads();
-  GridView grid;
-  grid.z = p.grid_z; grid.side = p.grid_side; grid.fast_div = p.grid_fast_div;
-  const float* wt = p.walk ? p.walk + (size_t)group * VIEW_WALK_STRIDE * 64 : nullptr;   // the group's walk tables, then its rays' ViewWalk members
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
   int pending = 0, waiting = 0;          // entries of the exact-order queue, of the fast queue
+  // The drains below take what they need of the kernel's arguments from the argument block again (kernarg_again) instead
+  // of from registers that would stay occupied across the survivor loop, which is short of scalar registers as it is.
   auto push_exact = [&](unsigned long long mask, uint32_t sidx, uint32_t ray) __attribute__((always_inline)) {
     if ((mask >> lane) & 1ull) q_pair[pending + (int)lanes_below(mask)] = (sidx << 6) | ray;
     pending += __builtin_popcountll(mask);
   };
   auto drain_exact = [&](int take) __attribute__((always_inline)) {
     __syncthreads();
-    if (lane < take && !(p.debug & 16)) {
+    const PB_CONST_AS RenderParams* q = kernarg_again<RenderParams>();
+    const float* rr = q->rays + (size_t)group * PB_RAY_WORDS * 64;
+    GridView grid;
+    grid.z = q->grid_z; grid.side = q->grid_side; grid.fast_div = q->grid_fast_div;
+    if (lane < take && !(q->debug & 16)) {
       const uint32_t pair = q_pair[pending - take + lane];
       const uint32_t sidx = pair >> 6, rl = pair & 63u;
       Ray rq;
@@ -2002,11 +2011,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       rq.maxd = rr[6 * 64 + rl];
       rq.d1 = v3(rr[8 * 64 + rl], rr[9 * 64 + rl], rr[10 * 64 + rl]);
       rq.active = true;
-      const SegFrame f = load_frame_wide(p.frames + sidx);
+      const SegFrame f = load_frame_wide(q->frames + sidx);
       CylHit hit;
       if (hit_cylinder_exact(f, rq, hit) == 2) {
-        const float4 A = p.capA[sidx];
-        double integral = integral_73het(grid, v3(A.x, A.y, A.z), p.het[sidx], p.het_axis[sidx], hit, rq, p.extinction_c, p.scattering_c);
+        const float4 A = q->capA[sidx];
+        double integral = integral_73het(grid, v3(A.x, A.y, A.z), q->het[sidx], q->het_axis[sidx], hit, rq, q->extinction_c, q->scattering_c);
         const double W0 = f.W[0], W1 = f.W[1], W2 = f.W[2];
         integral = fmin(integral, PB_FIX_LIMIT / fmax(W0, fmax(W1, W2)));
         integral = integral * PB_FIX_PRESCALE;
@@ -2024,14 +2033,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   // the second half of the estimator for the top `take` entries of the fast queue, one per lane
   auto drain_fast = [&](int take) __attribute__((always_inline)) {
     __syncthreads();
+    const PB_CONST_AS RenderParams* q = kernarg_again<RenderParams>();
+    const float* rr = q->rays + (size_t)group * PB_RAY_WORDS * 64;
+    const float* wt = q->walk ? q->walk + (size_t)group * VIEW_WALK_STRIDE * 64 : nullptr;   // the group's walk tables, then its rays' ViewWalk members
+    GridView grid;
+    grid.z = q->grid_z; grid.side = q->grid_side; grid.fast_div = q->grid_fast_div;
     bool defer = false;
     uint32_t sidx = 0, rl = 0;
-    if (lane < take && !(p.debug & 8)) {
+    if (lane < take && !(q->debug & 8)) {
       const int e = waiting - take + lane;
       const uint32_t key = fq_key[e];
       sidx = (key & 0x7fffffffu) >> 6; rl = key & 63u;
       const float t_mid = fq_val[0][e], y_star = fq_val[1][e], y_err = fq_val[2][e], sin2 = fq_val[3][e];
-      const float4* rec = (const float4*)(p.frames + sidx);
+      const float4* rec = (const float4*)(q->frames + sidx);
       bool passes = true;
       if (key & 0x80000000u) {
         // the segment's gate (HitBoundingBox entry against the ray's surface distance) for the ray this pair belongs to
@@ -2046,7 +2060,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       const float4 b0 = rec[4];                               // W[0], W[1]
       const float2 b1 = ((const float2*)rec)[10];             // W[2]
       const float vcap10 = ((const float*)rec)[31];
-      const float4* hrec = (const float4*)(p.het_fast + sidx);
+      const float4* hrec = (const float4*)(q->het_fast + sidx);
       const float4 h0 = hrec[0], h1 = hrec[1];                // r2, osy, aos, bos | A, B, krad, -
       const float len = a3.y;
       const uint32_t qflags = __builtin_bit_cast(uint32_t, a3.w);
@@ -2062,7 +2076,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         if (grid.z) w = view_walk_load(wt + VIEW_WALK_ROWS * 64, (int)rl);
         const float view_distance = t_mid * len;
         const float beam_extinction = __builtin_fmaf(h1.y, beta - h0.z, h1.x);
-        float view_extinction = p.extinction_c;
+        float view_extinction = q->extinction_c;
         if (grid.z) {
           const float cut = view_distance * w.d1_len;
           defer = cut >= w.t_unsure;           // the exact-order code evaluates this pair; the term added below is zero
@@ -2131,16 +2145,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     bool need_block = true;
     for (;;) {
       const bool flushing = need_block && b0 >= ns;
-      if (!FINALIZE && flushing && waiting == 0 && pending > 0 && pending < 64 && p.residue) {
+      if (!FINALIZE && flushing && waiting == 0 && pending > 0 && pending < 64 && kernarg_again<RenderParams>()->residue) {
         // fewer than a wave's worth left: they join one of the frame's residue queues (residue_kernel) if it has room
+        const PB_CONST_AS RenderParams* pa = kernarg_again<RenderParams>();
+        uint2* const residue = pa->residue;
         const uint32_t q = c & (uint32_t)(PB_RESIDUE_QUEUES - 1);
-        const uint32_t cap = pb_residue_queue_capacity(p.residue_capacity);
+        const uint32_t cap = pb_residue_queue_capacity(pa->residue_capacity);
         uint32_t at = 0;
-        if (lane == 0) at = atomicAdd((uint32_t*)p.residue + q * 32u, (uint32_t)pending);
+        if (lane == 0) at = atomicAdd((uint32_t*)residue + q * 32u, (uint32_t)pending);
         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
         const bool fits = at + (uint32_t)pending <= cap;
         __syncthreads();
-        uint2* dst = p.residue + PB_RESIDUE_HEAD + (size_t)q * cap;
+        uint2* dst = residue + PB_RESIDUE_HEAD + (size_t)q * cap;
         if (lane < pending && at + (uint32_t)lane < cap)
           dst[at + lane] = fits ? make_uint2(q_pair[lane] >> 6, ((uint32_t)group << 6) | (q_pair[lane] & 63u)) : make_uint2(0xffffffffu, 0u);
         if (fits) { pending = 0; continue; }
