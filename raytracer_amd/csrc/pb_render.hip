@@ -1373,8 +1373,19 @@ static_assert(sizeof(SegHalfA) == 64 && sizeof(SegHalfB) == 64, "halves of the f
 PB_DI void smem_load16(u32x16& dst, const SegFrame* base, uint32_t byte_offset) {
   asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(dst) : "s"(base), "s"(byte_offset));
 }
-PB_DI void smem_wait(u32x16& a, u32x16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
 PB_DI void smem_wait(u32x16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+// The compiler takes a register written by smem_load16 to hold its value from that statement on and to be free after
+// the last statement that names it, while the data arrives whenever the load completes: every path from a load has to
+// reach a wait that NAMES the destination, or the registers can be given to something else (a mask, a restored pointer)
+// with the load still in flight and the data lands on top of it.  tools/check_smem_inflight.py checks the assembly.
+//  - smem_wait_keep: a wait on a path only some lanes take.  A scalar register redefined under a divergent branch
+//    cannot be named after the branches join, so this one leaves `a` as it is and is tied to the two per-lane values
+//    everything downstream of it is computed from instead (what reads `a` there also reads one of them, or sits in a
+//    block entered on one of them).
+//  - smem_wait_both(a, kept): the wait every path reaches; names `kept` as well, so that its registers stay reserved on
+//    the paths that never looked at it.
+PB_DI void smem_wait_keep(const u32x16& a, float& x, float& y) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y) : "s"(a)); }
+PB_DI void smem_wait_both(u32x16& a, const u32x16& kept) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : "s"(kept)); }
 
 struct PairSums { unsigned long long ai[3]; unsigned long long ag; uint32_t nc, ng; };   // nc / ng: terms in ai / in ag
 
@@ -1394,7 +1405,7 @@ PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t 
     // be given a value on the paths that leave early
     pair_721_fast_crossing_then(qa, qb, b24ac, v3(a.Rinv[1], a.Rinv[4], a.Rinv[7]), a.oy, a.len, a.tb0, r.l, extinction, -10.0f,
                                 [&](float tc_minus, float value) __attribute__((always_inline)) {
-      smem_wait(second);            // (only `second`: a scalar register written under a divergent branch must not live past it)
+      smem_wait_keep(second, tc_minus, value);
       SegHalfB b;
       __builtin_memcpy(&b, &second, 64);
       bool ok = true;
@@ -1417,7 +1428,7 @@ PB_DI void pair_step(const SegFrame* frames, u32x16& cur, u32x16& nxt, uint32_t 
       }
     });
   }
-  smem_wait(nxt);               // on every path (both loads have landed then): the next step reads `nxt`
+  smem_wait_both(nxt, second);  // on every path (both loads have landed then): the next step reads `nxt`
 }
 
 // What an evaluation item does with its lane sums: adds them to its tile's accumulators and, where the frame has no
@@ -1494,7 +1505,7 @@ PB_DI void item_writeout(const RenderParams& p, int tile, int lane, const PairSu
 // looks, the wave writes).  The sums of tiles with several items and their arrival counters are zero when the frame
 // starts because the last arriver of the frame before left them so.
 template <bool FINALIZE, bool INLINE = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_items_fast_kernel(const RenderParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void eval_items_fast_kernel(const RenderParams p) {
   __shared__ uint32_t surv[INLINE ? 1 : PB_SLICE];
   const int lane = threadIdx.x;
   if (INLINE && (int)blockIdx.x >= p.inline_item_blocks) {
