@@ -14,7 +14,8 @@ reaching it, i.e. with no `s_waitcnt ... lgkmcnt(0)` in between.
 
     python tools/check_smem_inflight.py raytracer_amd/csrc/pb_render.hip [more.hip ...]
 
-Exit status 1 if anything is reported.  `make -C raytracer_amd/csrc lint` runs it over the sources that use the idiom.
+A `.s` file is read as it is (device assembly, as `hipcc -S --cuda-device-only` writes it).  Exit status 1 if anything
+is reported.  raytracer_amd/csrc/Makefile runs it on pb_render.hip's assembly before it makes the object.
 """
 import os
 import re
