@@ -124,7 +124,7 @@ void pb_tune_reload() {
   t.debug_times = std::getenv("PB_DEBUG_TIMES") != nullptr; t.emit_twice = std::getenv("PB_TUNE_EMIT_TWICE") != nullptr;
   t.het1 = std::getenv("PB_TUNE_HET1") != nullptr; t.het2 = std::getenv("PB_TUNE_HET2") != nullptr;
   t.old_eval = std::getenv("PB_OLD_EVAL") != nullptr; t.no_residue = std::getenv("PB_TUNE_NO_RESIDUE") != nullptr;
-  t.wide = std::getenv("PB_TUNE_WIDE") != nullptr;
+  t.wide = std::getenv("PB_TUNE_WIDE") != nullptr; t.het_lds_list = std::getenv("PB_TUNE_HET_LDS_LIST") != nullptr;
   g_tune = t;
 }
 

@@ -1961,9 +1961,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 constexpr int HET2_SLICE = 256;       // candidates of an item of this kernel (het_two_pass): with the queues below, 7.5 KB of LDS a wave
 constexpr int FAST_QUEUE = 192;       // up to 63 waiting + two survivors' worth of lanes between two looks at the queue
 constexpr int EXACT_QUEUE = 192;      // likewise: 63 + two survivors, or 63 + what one drain of the fast queue hands over
-template <bool FINALIZE, bool WIDE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void eval_items_het2_kernel(const RenderParams p) {
-  __shared__ uint32_t surv[HET2_SLICE];
+// KEPT: every item is one of a kept queue (its survivors lie in surv_list and are read from there): without the list
+// in LDS a wave needs 6.5 KB, and six waves fit a SIMD where five did.
+template <bool FINALIZE, bool WIDE, bool KEPT = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KEPT ? 6 : 5, KEPT ? 6 : 5))) void eval_items_het2_kernel(const RenderParams p) {
+  __shared__ uint32_t surv[KEPT ? 1 : HET2_SLICE];
   __shared__ uint32_t fq_key[FAST_QUEUE];                 // segment * 64 + ray (lane) of a pair whose crossing holds its closest approach
   __shared__ float fq_val[4][FAST_QUEUE];                 // t_mid, y*, the margin on y*, sin^2(theta)
   __shared__ uint32_t q_pair[EXACT_QUEUE];                // pairs left to the exact-order code: segment * 64 + ray
@@ -1985,8 +1987,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   const int cn = (int)it[2];
   const int tile = group / (p.ssaa * p.ssaa);
   const float* rr = p.rays + (size_t)group * PB_RAY_WORDS * 64;
-  V3 pl[4];
-  {
+  V3 pl[4] = {};
+  if (!KEPT) {
     const PB_CONST_AS float* w = pb_uniform(rr + 7 * 64);
     pl[0] = v3(w[0], w[1], w[2]); pl[1] = v3(w[3], w[4], w[5]); pl[2] = v3(w[6], w[7], w[8]); pl[3] = v3(w[9], w[10], w[11]);
   }
@@ -1996,7 +1998,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   r.maxd = rr[6 * 64 + lane];
   r.d1 = r.dn;
   r.active = r.maxd >= 0.0f;
-  int ns = refine_candidates<true>(p, start, cn, pl, surv, lane, it[3]);
+  const uint32_t* kept = p.surv_list + start;
+  int ns = KEPT ? cn : refine_candidates<true>(p, start, cn, pl, surv, lane, it[3]);
   s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull; s_acc[3][lane] = 0ull;
   __syncthreads();
   const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(PB_FIX_MAGIC);
@@ -2177,7 +2180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       if (flushing) break;
       if (need_block) {
         nb = (ns - b0) < 64 ? (ns - b0) : 64;
-        mine = (lane < nb) ? (int)surv[b0 + lane] : 0;
+        mine = (lane < nb) ? (int)(KEPT ? kept[b0 + lane] : surv[b0 + lane]) : 0;
         idx_cur = (uint32_t)__builtin_amdgcn_readlane(mine, 0);
         if (WIDE) smem_load16_first(ra, p.frames + idx_cur);
         else smem_load16(ra, p.frames, idx_cur * (uint32_t)sizeof(SegFrame));
@@ -2585,6 +2588,7 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
       if (pb_residue_frame(p, mode)) {
         // the items hand the pairs they leave to the exact-order code to one more launch; the pixels are written after it
         if (wide) hipLaunchKernelGGL((eval_items_het2_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
+        else if (p.kept_queue && !pb_tune().het_lds_list) hipLaunchKernelGGL((eval_items_het2_kernel<false, false, true>), dim3(waves), dim3(64), 0, s, p);
         else hipLaunchKernelGGL((eval_items_het2_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
         hipLaunchKernelGGL(residue_kernel, dim3(PB_RESIDUE_QUEUES * RESIDUE_BLOCKS_PER_QUEUE), dim3(64), 0, s, p);
       } else if (p.finalize_in_eval) {
