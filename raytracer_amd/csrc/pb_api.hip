@@ -125,6 +125,7 @@ void pb_tune_reload() {
   t.het1 = std::getenv("PB_TUNE_HET1") != nullptr; t.het2 = std::getenv("PB_TUNE_HET2") != nullptr;
   t.old_eval = std::getenv("PB_OLD_EVAL") != nullptr; t.no_residue = std::getenv("PB_TUNE_NO_RESIDUE") != nullptr;
   t.wide = std::getenv("PB_TUNE_WIDE") != nullptr; t.het_lds_list = std::getenv("PB_TUNE_HET_LDS_LIST") != nullptr;
+  t.het1_lds_tab = std::getenv("PB_TUNE_HET1_LDS_TAB") != nullptr;
   g_tune = t;
 }
 

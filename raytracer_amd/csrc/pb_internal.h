@@ -265,7 +265,7 @@ struct PbTune {
   int surv = -1, fused_max = -1, macrow = -1, macroh = -1, xcdrun = -1, whole = -1, slice = -1, waves = -1, raywaves = -1, debug = 0;
   double inline_ratio = -1.0;
   bool no_prefine = false, no_keep = false, separate_finalize = false, refill = false, debug_times = false, emit_twice = false,
-       het1 = false, het2 = false, old_eval = false, no_residue = false, wide = false, het_lds_list = false;
+       het1 = false, het2 = false, old_eval = false, no_residue = false, wide = false, het_lds_list = false, het1_lds_tab = false;
 };
 const PbTune& pb_tune();
 void pb_tune_reload();

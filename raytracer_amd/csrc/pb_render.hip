@@ -1806,10 +1806,13 @@ __global__ __launch_bounds__(64) void view_walk_kernel(const RenderParams p) {
   view_walk_store(w, wt + VIEW_WALK_ROWS * 64, lane);
 }
 
-template <bool FINALIZE, bool WIDE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void eval_items_het_kernel(const RenderParams p) {
+// LDS_TAB: the rays' walk tables are copied to LDS (10 KB a wave: eleven waves a CU); without, a valid pair's three
+// look-ups go to the tables in global memory and four waves fit a SIMD (4096^2 rays, 23.7 M segments, eight bands:
+// 2.42 -> 1.78 s a frame).
+template <bool FINALIZE, bool WIDE, bool LDS_TAB>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LDS_TAB ? 3 : 4, 4))) void eval_items_het_kernel(const RenderParams p) {
   __shared__ uint32_t surv[PB_SLICE];
-  __shared__ float tab[VIEW_WALK_ROWS * 64];
+  __shared__ float tab[LDS_TAB ? VIEW_WALK_ROWS * 64 : 1];
   __shared__ uint32_t q_seg[HIT_QUEUE], q_ray[HIT_QUEUE];
   __shared__ unsigned long long s_acc[3][64];
   const int lane = threadIdx.x;
@@ -1851,8 +1854,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     // the rays' tabulated walks (view_walk_kernel): members to registers, tables to LDS
     const float* wt = p.walk + (size_t)group * VIEW_WALK_STRIDE * 64;
     h.walk = view_walk_load(wt + VIEW_WALK_ROWS * 64, lane);
+    if (LDS_TAB) {
 #pragma unroll 8
-    for (int row = 0; row < VIEW_WALK_ROWS; ++row) tab[row * 64 + lane] = wt[row * 64 + lane];
+      for (int row = 0; row < VIEW_WALK_ROWS; ++row) tab[row * 64 + lane] = wt[row * 64 + lane];
+    } else h.tab = wt;
   }
   s_acc[0][lane] = 0ull; s_acc[1][lane] = 0ull; s_acc[2][lane] = 0ull;
   __syncthreads();
@@ -2585,6 +2590,7 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
       if (p.xcd_run > 0) waves = (waves + 8 * p.xcd_run - 1) / (8 * p.xcd_run) * (8 * p.xcd_run);    // whole runs for every XCD
       const bool wide = wide_records(p) || pb_tune().wide;
       const bool two_pass = het_two_pass(p);
+      const bool lds_tab = pb_tune().het1_lds_tab;       // the one-pass kernel with its walk tables in LDS, as it was (for A/B)
       if (pb_residue_frame(p, mode)) {
         // the items hand the pairs they leave to the exact-order code to one more launch; the pixels are written after it
         if (wide) hipLaunchKernelGGL((eval_items_het2_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
@@ -2594,15 +2600,19 @@ static int launch_eval_finalize(const RenderParams& p, int mode, bool count, hip
       } else if (p.finalize_in_eval) {
         if (two_pass && wide) hipLaunchKernelGGL((eval_items_het2_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
         else if (two_pass) hipLaunchKernelGGL((eval_items_het2_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
-        else if (wide) hipLaunchKernelGGL((eval_items_het_kernel<true, true>), dim3(waves), dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((eval_items_het_kernel<true, false>), dim3(waves), dim3(64), 0, s, p);
+        else if (wide && lds_tab) hipLaunchKernelGGL((eval_items_het_kernel<true, true, true>), dim3(waves), dim3(64), 0, s, p);
+        else if (wide) hipLaunchKernelGGL((eval_items_het_kernel<true, true, false>), dim3(waves), dim3(64), 0, s, p);
+        else if (lds_tab) hipLaunchKernelGGL((eval_items_het_kernel<true, false, true>), dim3(waves), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((eval_items_het_kernel<true, false, false>), dim3(waves), dim3(64), 0, s, p);
         PB_HIP(hipGetLastError());
         return PB_OK;
       }
       else if (two_pass && wide) hipLaunchKernelGGL((eval_items_het2_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
       else if (two_pass) hipLaunchKernelGGL((eval_items_het2_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
-      else if (wide) hipLaunchKernelGGL((eval_items_het_kernel<false, true>), dim3(waves), dim3(64), 0, s, p);
-      else hipLaunchKernelGGL((eval_items_het_kernel<false, false>), dim3(waves), dim3(64), 0, s, p);
+      else if (wide && lds_tab) hipLaunchKernelGGL((eval_items_het_kernel<false, true, true>), dim3(waves), dim3(64), 0, s, p);
+      else if (wide) hipLaunchKernelGGL((eval_items_het_kernel<false, true, false>), dim3(waves), dim3(64), 0, s, p);
+      else if (lds_tab) hipLaunchKernelGGL((eval_items_het_kernel<false, false, true>), dim3(waves), dim3(64), 0, s, p);
+      else hipLaunchKernelGGL((eval_items_het_kernel<false, false, false>), dim3(waves), dim3(64), 0, s, p);
     }
     else hipLaunchKernelGGL(eval_bins_queue_kernel<PB_MODE_73HET>, dim3(waves), dim3(64), 0, s, p);
   }

@@ -177,11 +177,15 @@ def test_het_render_matches_oracle(pb):
         # code) and as the one-pass kernel very large segment sets take: the same bits
         wide = []
         for env in (dict(PB_TUNE_WIDE="1"), dict(PB_TUNE_WIDE="1", PB_TUNE_FUSED_MAX="0"), dict(PB_TUNE_NO_RESIDUE="1"),
-                    dict(PB_TUNE_HET1="1"), dict(PB_TUNE_HET1="1", PB_TUNE_WIDE="1")):
+                    dict(PB_TUNE_HET1="1"), dict(PB_TUNE_HET1="1", PB_TUNE_WIDE="1"),
+                    # the one-pass kernel with its walk tables in LDS (three waves a SIMD), the two-pass kernel with a kept
+                    # queue's survivors copied to LDS (five): the forms both had before, kept for A/B
+                    dict(PB_TUNE_HET1="1", PB_TUNE_HET1_LDS_TAB="1"), dict(PB_TUNE_HET1="1", PB_TUNE_WIDE="1", PB_TUNE_HET1_LDS_TAB="1"),
+                    dict(PB_TUNE_HET_LDS_LIST="1")):
             os.environ.update(env)
             pb.reload_tuning()
             try:
-                wide.extend(ctx.draw(mode=pb.MODE_73HET, cull="bins") for _ in range(2))
+                wide.extend(ctx.draw(mode=pb.MODE_73HET, cull="bins") for _ in range(3))   # the third runs the kept queue
             finally:
                 for k in env:
                     del os.environ[k]
