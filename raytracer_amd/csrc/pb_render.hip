@@ -1808,9 +1808,9 @@ __global__ __launch_bounds__(64) void view_walk_kernel(const RenderParams p) {
 
 // LDS_TAB: the rays' walk tables are copied to LDS (10 KB a wave: eleven waves a CU); without, a valid pair's three
 // look-ups go to the tables in global memory and four waves fit a SIMD (4096^2 rays, 23.7 M segments, eight bands:
-// 2.42 -> 1.78 s a frame).
+// 2.42 -> 1.78 s a frame); five, with 96 registers and 55 dwords a lane in scratch, 1.72 s.
 template <bool FINALIZE, bool WIDE, bool LDS_TAB>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LDS_TAB ? 3 : 4, 4))) void eval_items_het_kernel(const RenderParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LDS_TAB ? 3 : 5, LDS_TAB ? 4 : 5))) void eval_items_het_kernel(const RenderParams p) {
   __shared__ uint32_t surv[PB_SLICE];
   __shared__ float tab[LDS_TAB ? VIEW_WALK_ROWS * 64 : 1];
   __shared__ uint32_t q_seg[HIT_QUEUE], q_ray[HIT_QUEUE];
